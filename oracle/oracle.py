@@ -1,0 +1,174 @@
+"""ctypes front end of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the shipped encoder never does.  The shared object is built by
+``make -C oracle`` (or ``__graft_entry__.build()``) into ``oracle/_build``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libjpeg_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "jpeg_oracle.cpp")
+    if force or not os.path.exists(_SO) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.orc_encode.restype = C.c_void_p
+        L.orc_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_int]
+        L.orc_free.argtypes = [C.c_void_p]
+        for name in ("orc_jpeg_size", "orc_scan_offset", "orc_scan_len"):
+            getattr(L, name).restype = C.c_int64
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.orc_jpeg_copy.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_coef_count.restype = C.c_int64
+        L.orc_coef_count.argtypes = [C.c_void_p, C.c_int]
+        L.orc_coef_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_hist_copy.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_table_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_dims.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_constants.argtypes = [C.c_void_p]
+        L.orc_color_convert.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.orc_dct_block.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_dct_quant_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_huffman.restype = C.c_int
+        L.orc_huffman.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_bitbuffer_replay.restype = C.c_int64
+        L.orc_bitbuffer_replay.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                           C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def constants():
+    out = np.zeros(12, np.float32)
+    lib().orc_constants(_p(out))
+    return out
+
+
+def color_convert(r, g, b):
+    out = np.zeros(3, np.float32)
+    lib().orc_color_convert(np.float32(r), np.float32(g), np.float32(b), _p(out))
+    return out
+
+
+def dct_block(block):
+    a = np.ascontiguousarray(block, np.float32).reshape(64)
+    out = np.zeros(64, np.float32)
+    lib().orc_dct_block(_p(a), _p(out))
+    return out.reshape(8, 8)
+
+
+def dct_quant_block(block01, qtable):
+    a = np.ascontiguousarray(block01, np.float32).reshape(64)
+    q = np.ascontiguousarray(qtable, np.float32).reshape(64)
+    out = np.zeros(64, np.float32)
+    lib().orc_dct_quant_block(_p(a), _p(q), _p(out))
+    return out.reshape(8, 8)
+
+
+def huffman(counts, ht_num=0, ht_type=0):
+    """-> (lengths[256] u8, codes[256] u16, dht segment bytes)."""
+    cnt = np.ascontiguousarray(counts, np.uint64).reshape(256)
+    lengths = np.zeros(256, np.uint8)
+    codes = np.zeros(256, np.uint16)
+    dht = np.zeros(2 + 2 + 1 + 16 + 256, np.uint8)
+    n = lib().orc_huffman(_p(cnt), ht_num, ht_type, _p(lengths), _p(codes), _p(dht), dht.size)
+    assert n >= 0
+    return lengths, codes, dht[:n].tobytes()
+
+
+def bitbuffer_replay(pushes, escape=True, fill=True):
+    """pushes: list of (nbits, value) with value right-aligned; -> (bytes, bit length)."""
+    n = len(pushes)
+    nbits = np.zeros(max(n, 1), np.int32)
+    src = np.zeros((max(n, 1), 4), np.uint8)
+    for i, (nb, v) in enumerate(pushes):
+        nbits[i] = nb
+        if nb:
+            w = (int(v) & ((1 << nb) - 1)) << (32 - nb)
+            src[i] = [(w >> 24) & 255, (w >> 16) & 255, (w >> 8) & 255, w & 255]
+    cap = 16 + 4 * n * 2
+    out = np.zeros(cap, np.uint8)
+    bitlen = C.c_int64(0)
+    ln = lib().orc_bitbuffer_replay(n, _p(nbits), _p(src), int(escape), int(fill), _p(out), cap, C.byref(bitlen))
+    assert ln >= 0
+    return out[:ln].tobytes(), bitlen.value
+
+
+class Encoded:
+    """Everything the oracle produced for one image."""
+
+    def __init__(self, jpeg, coef, hist, lengths, codes, scan_offset, scan_len, dims):
+        self.jpeg = jpeg
+        self.coef = coef            # list of 3 int16 arrays [blocks, 64] (MCU order, zig-zag)
+        self.hist = hist            # uint64 [4, 256]: DC-Y, DC-C, AC-Y, AC-C
+        self.lengths = lengths      # uint8 [4, 256]
+        self.codes = codes          # uint16 [4, 256]
+        self.scan_offset = scan_offset
+        self.scan_len = scan_len
+        self.sim_w, self.sim_h = int(dims[0]), int(dims[1])
+        self.channel_sizes = [(int(dims[2 + 2 * c]), int(dims[3 + 2 * c])) for c in range(3)]
+
+    @property
+    def scan(self):
+        return self.jpeg[self.scan_offset:self.scan_offset + self.scan_len]
+
+
+def encode(rgb, scheme, qtables, restart_interval=0, pad_ones=False, stride=None):
+    """rgb: uint8 or float32 array [H, W, 3]; scheme: 12 ints; qtables: float32 [3, 64]."""
+    L = lib()
+    rgb = np.asarray(rgb)
+    h, w = rgb.shape[0], rgb.shape[1]
+    if rgb.dtype == np.uint8:
+        st = 0
+    elif rgb.dtype == np.float32:
+        st = 1
+    else:
+        raise TypeError("rgb must be uint8 or float32")
+    rgb = np.ascontiguousarray(rgb)
+    if stride is None:
+        stride = w * 3
+    sch = np.ascontiguousarray(scheme, np.int32).reshape(12)
+    qt = np.ascontiguousarray(qtables, np.float32).reshape(3, 64)
+    hnd = L.orc_encode(_p(rgb), st, w, h, stride, _p(sch), _p(qt), int(restart_interval), int(pad_ones))
+    try:
+        n = L.orc_jpeg_size(hnd)
+        jpeg = np.zeros(n, np.uint8)
+        L.orc_jpeg_copy(hnd, _p(jpeg))
+        coef = []
+        for c in range(3):
+            cnt = L.orc_coef_count(hnd, c)
+            a = np.zeros(cnt, np.int16)
+            L.orc_coef_copy(hnd, c, _p(a))
+            coef.append(a.reshape(-1, 64))
+        hist = np.zeros((4, 256), np.uint64)
+        L.orc_hist_copy(hnd, _p(hist))
+        lengths = np.zeros((4, 256), np.uint8)
+        codes = np.zeros((4, 256), np.uint16)
+        for t in range(4):
+            L.orc_table_copy(hnd, t, _p(lengths[t]), _p(codes[t]))
+        dims = np.zeros(8, np.int32)
+        L.orc_dims(hnd, _p(dims))
+        return Encoded(jpeg.tobytes(), coef, hist, lengths, codes, L.orc_scan_offset(hnd), L.orc_scan_len(hnd), dims)
+    finally:
+        L.orc_free(hnd)
