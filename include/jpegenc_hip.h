@@ -1,0 +1,210 @@
+/*
+ * jpegenc_hip.h -- C ABI of the MI355X (gfx950) baseline-JPEG encode hot path.
+ *
+ * The library replaces what sits behind the reference's Encoder / Image / ImageLoader
+ * classes (Irame/JPEG-Encoder, tree "JPEG-Encoder-SIMD/"): colour conversion, chroma
+ * subsampling, 8x8 AAN DCT, quantization, zig-zag, DC/AC symbol generation, per-image
+ * length-limited Huffman tables and the escaped bit stream.  Plain C types only, caller
+ * owned buffers, integer status codes, no exceptions across the boundary.  Every entry
+ * point names the reference interface it stands in for.
+ *
+ * Pointer naming: d_* is device (HBM) memory of the context's GPU, h_* is host memory.
+ * All device work of a context runs on one HIP stream; entry points that return data
+ * to the host synchronise that stream before they return.
+ */
+#ifndef JPEGENC_HIP_H
+#define JPEGENC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jpeg_hip_ctx jpeg_hip_ctx;
+
+enum {
+    JPEG_HIP_OK = 0,
+    JPEG_HIP_ERR_INVALID_ARGUMENT = -1,
+    JPEG_HIP_ERR_HIP = -2,              /* a HIP runtime call failed; see jpeg_hip_last_error */
+    JPEG_HIP_ERR_BUFFER_TOO_SMALL = -3,
+    JPEG_HIP_ERR_BAD_STATE = -4,        /* staged entry points called out of order */
+    JPEG_HIP_ERR_NO_DEVICE = -5
+};
+
+/* ReductionMethod, SamplingScheme.h:4-7 */
+enum { JPEG_HIP_SUBSAMPLING = 0, JPEG_HIP_AVERAGE = 1 };
+
+/* Encoder::CoefficientType, Encoder.h:9-12 */
+enum { JPEG_HIP_DC = 0, JPEG_HIP_AC = 1 };
+
+/* Sample layout of the interleaved RGB input. */
+enum {
+    JPEG_HIP_RGB8 = 0,   /* bytes; value/255.0f is applied as ImageLoader::LoadPNG does (ImageLoader.cpp:190-193) */
+    JPEG_HIP_RGBF32 = 1  /* floats in [0,1], the layout Image::setRawPixelData takes (Image.h:89) */
+};
+
+/* Transform stages, one bit per reference call that the fused kernel absorbs. */
+enum {
+    JPEG_HIP_STAGE_YCBCR = 1,     /* Encoder::convertToYCbCr, Encoder.cpp:15-23 */
+    JPEG_HIP_STAGE_SUBSAMPLE = 2, /* Encoder::reduceResolutionBySchema, Encoder.cpp:157-166 */
+    JPEG_HIP_STAGE_ALL = 3
+};
+
+/*
+ * Geometry and tables of one image (or one band of a large image).
+ *
+ * sampling: SamplingDefinition (SamplingScheme.h:25-44) -- per channel Y, Cb, Cr the four
+ *   ChannelReductionOptions fields {widthFactor, widthMethod, heightFactor, heightMethod}.
+ * qtable:   QTableSet (QuantizationTables.h:11-27) -- three tables of 64 floats in natural
+ *   (row-major) order.
+ * restart_interval: MCUs per restart interval; 0 reproduces the reference (one scan, no
+ *   DRI/RSTn).  No counterpart in the reference.
+ * pad_ones: 0 pads the last byte of the scan (and of every restart interval) with zero
+ *   bits as BitBuffer::fillToByteBorder does (BitBuffer.cpp:12-16); 1 pads with one bits.
+ * mcu_row_begin / mcu_row_end: the band of MCU rows this context encodes, for images
+ *   sharded over several GPUs; both 0 selects the whole image.  A band must start on a
+ *   restart-interval boundary.  The RGB pointer handed to the encode calls addresses
+ *   image row mcu_row_begin * (MCU height).  No counterpart in the reference.
+ */
+typedef struct jpeg_hip_params {
+    int32_t width;
+    int32_t height;
+    int32_t sampling[12];
+    float qtable[3][64];
+    int32_t restart_interval;
+    int32_t pad_ones;
+    int32_t mcu_row_begin;
+    int32_t mcu_row_end;
+} jpeg_hip_params;
+
+/* Derived sizes (Image::Image, Image.cpp:6-16; Encoder::createBlocks, Encoder.cpp:168-227). */
+typedef struct jpeg_hip_layout {
+    int32_t padded_width, padded_height;  /* "simulated" size */
+    int32_t mcu_width, mcu_height;        /* SamplingDefinition::stepSize */
+    int32_t mcus_per_row, mcu_rows;       /* whole image */
+    int32_t band_mcu_rows;                /* rows encoded by this context */
+    int32_t h_factor[3], v_factor[3];     /* SamplingDefinition::inverseFactor */
+    int32_t blocks_per_mcu;
+    int64_t blocks[3];                    /* 8x8 blocks per channel in the band */
+    int64_t total_blocks;
+    int64_t intervals;                    /* restart intervals in the band (1 without restarts) */
+    int64_t max_jpeg_bytes;               /* safe output capacity for jpeg_hip_encode */
+} jpeg_hip_layout;
+
+/* ---- context ------------------------------------------------------------------------ */
+
+/* Opens a context on a GPU.  Stands in for constructing the reference's Encoder
+ * (Encoder.cpp:7-13); the device workspace grows on demand and is reused across images. */
+int jpeg_hip_create(int device_id, jpeg_hip_ctx** out_ctx);
+void jpeg_hip_destroy(jpeg_hip_ctx* ctx);
+/* Text of the last error recorded on the context (never NULL). */
+const char* jpeg_hip_last_error(const jpeg_hip_ctx* ctx);
+const char* jpeg_hip_status_string(int status);
+/* HIP stream the context launches on (a hipStream_t), for callers that time or order work. */
+void* jpeg_hip_stream(jpeg_hip_ctx* ctx);
+
+/* Pure host helper: sizes for a parameter block (no GPU needed). */
+int jpeg_hip_compute_layout(const jpeg_hip_params* params, jpeg_hip_layout* out_layout);
+
+/* ---- one-shot encode ------------------------------------------------------------------ */
+
+/* The whole of EncodeJPEG between "pixels in memory" and "file bytes in memory"
+ * (JPEG-Encoder-SIMD.cpp:421-437 + Encoder::serialize, Encoder.cpp:439-488), input and
+ * output resident in HBM.  d_rgb: interleaved RGB, row stride in bytes.  On success
+ * *out_len receives the JFIF length. */
+int jpeg_hip_encode(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
+                    const jpeg_hip_params* params, uint8_t* d_out, int64_t out_capacity, int64_t* out_len);
+
+/* Same with host buffers (copies in and out; PCIe time included). */
+int jpeg_hip_encode_host(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format, int64_t stride_bytes,
+                         const jpeg_hip_params* params, uint8_t* h_out, int64_t out_capacity, int64_t* out_len);
+
+/* ---- staged entry points (what the host Encoder class drives) --------------------------- */
+
+/* Image(w, h, scheme) + Encoder(image, qtables): fixes geometry and tables, sizes the
+ * workspace (Image.cpp:6-16, Encoder.cpp:11-13). */
+int jpeg_hip_begin(jpeg_hip_ctx* ctx, const jpeg_hip_params* params);
+
+/* Image::setRawPixelData / ImageLoader::LoadPNG hand-over (Image.cpp:63-139,
+ * ImageLoader.cpp:190-196): copies host pixels into the context's own device buffer. */
+int jpeg_hip_upload_pixels(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format, int64_t stride_bytes);
+/* Zero-copy variant: uses caller-owned device pixels, which must stay valid until the
+ * transform has run. */
+int jpeg_hip_bind_pixels(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes);
+
+/* convertToYCbCr + reduceResolutionBySchema + applyDCT(Y|Cb|Cr) + zig-zag as one fused
+ * kernel (Encoder.cpp:15-23, 157-166, 229-258; SIMD256.h:155-186, 260-304, 470-522;
+ * ZigZag.h:10-49).  stages: JPEG_HIP_STAGE_* bits for the two calls a caller may have
+ * skipped.  Leaves quantized int16 coefficients in HBM: blocks in scan (MCU interleaved)
+ * order, 64 zig-zag ordered values per block. */
+int jpeg_hip_transform(jpeg_hip_ctx* ctx, int stages);
+
+/* calculateDCValues / calculateACValues symbol statistics (Encoder.cpp:260-352) reduced
+ * to the four histograms createHuffmanTable counts (Encoder.cpp:368-416): DC-Y, DC-CbCr,
+ * AC-Y, AC-CbCr, 256 bins each.  d_hist (uint64[4][256]) is overwritten. */
+int jpeg_hip_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist);
+/* Same, copied to the host. */
+int jpeg_hip_histograms_host(jpeg_hip_ctx* ctx, uint64_t* h_hist);
+
+/* HuffmanTable<byte>::create(16, symbols) (HuffmanCodingByte.h:102-210) from a histogram:
+ * package-merge code lengths (<= 16) and right-growing codes.  Pure host function.
+ * lengths[s] == 0 marks an unused symbol; codes are right aligned. */
+int jpeg_hip_huffman_from_histogram(const uint64_t counts[256], uint8_t lengths[256], uint16_t codes[256]);
+
+/* DefineHuffmannTable segment (JPEGSegments.h:102-140, 203-207) for a table.  Returns the
+ * number of bytes written, or a negative status. */
+int jpeg_hip_write_dht(const uint8_t lengths[256], const uint16_t codes[256], int table_id, int coefficient_type,
+                       uint8_t* h_out, int capacity);
+
+/* Everything Encoder::serialize emits before the scan (Encoder.cpp:473-483): SOI, APP0,
+ * SOF0, DHT x4, DQT x3, [DRI], SOS.  Pure host function.  Returns bytes written or a
+ * negative status. */
+int jpeg_hip_write_headers(const jpeg_hip_params* params, const uint8_t lengths[4][256], const uint16_t codes[4][256],
+                           uint8_t* h_out, int capacity);
+
+/* Encoder::getHuffmanTable x4 (Encoder.cpp:418-437) for tables built elsewhere (e.g. from
+ * histograms summed over several GPUs).  Order: DC-Y, DC-CbCr, AC-Y, AC-CbCr. */
+int jpeg_hip_set_huffman(jpeg_hip_ctx* ctx, const uint8_t lengths[4][256], const uint16_t codes[4][256]);
+/* Builds the four tables from host histograms and installs them (create x4 + set). */
+int jpeg_hip_build_huffman(jpeg_hip_ctx* ctx, const uint64_t h_hist[4][256]);
+/* Copies the installed tables out (Encoder::getHuffmanTable). */
+int jpeg_hip_get_huffman(jpeg_hip_ctx* ctx, uint8_t lengths[4][256], uint16_t codes[4][256]);
+
+/* Encoder::serializeScanData (Encoder.cpp:490-516) with BitBuffer::pushBitsEscaped
+ * semantics (BitBuffer.cpp:128-204): writes the entropy coded segment of this band
+ * (RSTn markers between its restart intervals, and in front of its first interval when
+ * the band does not start the image) to d_out.  *out_len receives its length. */
+int jpeg_hip_emit_scan(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t out_capacity, int64_t* out_len);
+
+/* Quantized coefficients of one channel copied to the host: blocks in the channel's MCU
+ * order (Encoder::createBlocks), 64 zig-zag ordered int16 per block -- the values
+ * Encoder::calculateDCValues/ACValues read (Encoder.cpp:268-269, 308-309). */
+int jpeg_hip_get_coefficients(jpeg_hip_ctx* ctx, int channel, int16_t* h_out, int64_t capacity_values);
+/* Device pointer of the scan-ordered coefficient buffer (int16, total_blocks * 64). */
+const int16_t* jpeg_hip_coefficients_device(jpeg_hip_ctx* ctx);
+
+/* ---- sharded images (one band per GPU) ---------------------------------------------- */
+
+/* First half of a sharded encode: transform + histograms of this band.  The caller sums
+ * d_hist over all bands (one all-reduce) before calling jpeg_hip_finish_band. */
+int jpeg_hip_analyze_band(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
+                          const jpeg_hip_params* params, uint64_t* d_hist);
+/* Second half: tables from the summed histograms (host copy made internally), then this
+ * band's piece of the file: headers if the band starts the image, the band's scan bytes,
+ * EOI if the band ends the image.  Concatenating the pieces in band order gives the file. */
+int jpeg_hip_finish_band(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t* d_out, int64_t out_capacity,
+                         int64_t* out_len);
+
+/* Timing of the last jpeg_hip_encode / analyze / finish in milliseconds, measured with HIP
+ * events on the context's stream: [0] fused transform kernel, [1] histogram kernel,
+ * [2] entropy kernels (bit lengths, scans, bit writer, stuffing), [3] host table build.
+ * Only filled while profiling is enabled. */
+int jpeg_hip_set_profiling(jpeg_hip_ctx* ctx, int enabled);
+int jpeg_hip_get_timings(jpeg_hip_ctx* ctx, float out_ms[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPEGENC_HIP_H */

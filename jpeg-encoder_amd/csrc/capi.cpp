@@ -1,0 +1,625 @@
+// C ABI of libjpegenc_hip: context, workspace and orchestration of the kernels.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "internal.h"
+#include "kernels.h"
+
+using namespace jpeghip;
+
+namespace jpeghip {
+
+static int gcd_i(int a, int b) { return b == 0 ? a : gcd_i(b, a % b); }
+static int lcm_i(int a, int b) { return a / gcd_i(a, b) * b; }
+
+int make_geometry(const jpeg_hip_params& p, Geometry& g) {
+    if (p.width < 1 || p.height < 1 || p.width > 65535 || p.height > 65535) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    for (int c = 0; c < 3; ++c) {
+        g.wf[c] = p.sampling[4 * c];
+        g.wm[c] = p.sampling[4 * c + 1];
+        g.hf[c] = p.sampling[4 * c + 2];
+        g.hm[c] = p.sampling[4 * c + 3];
+        if (g.wf[c] < 1 || g.wf[c] > 4 || g.hf[c] < 1 || g.hf[c] > 4) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+        if ((g.wm[c] != JPEG_HIP_SUBSAMPLING && g.wm[c] != JPEG_HIP_AVERAGE) ||
+            (g.hm[c] != JPEG_HIP_SUBSAMPLING && g.hm[c] != JPEG_HIP_AVERAGE))
+            return JPEG_HIP_ERR_INVALID_ARGUMENT;
+        for (int i = 0; i < 64; ++i) {
+            const float q = p.qtable[c][i];
+            if (!(q >= 1.0f && q <= 255.0f) || q != std::floor(q)) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+        }
+    }
+    if (p.restart_interval < 0 || p.restart_interval > 65535) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    g.width = p.width;
+    g.height = p.height;
+    g.stepW = lcm_i(lcm_i(g.wf[0], g.wf[1]), g.wf[2]) * 8;   // SamplingScheme.h:36-38
+    g.stepH = lcm_i(lcm_i(g.hf[0], g.hf[1]), g.hf[2]) * 8;
+    g.simW = (p.width + g.stepW - 1) / g.stepW * g.stepW;    // Image.cpp:8-10
+    g.simH = (p.height + g.stepH - 1) / g.stepH * g.stepH;
+    g.mcusPerRow = g.simW / g.stepW;
+    g.mcuRows = g.simH / g.stepH;
+    g.blocksPerMcu = 0;
+    for (int c = 0; c < 3; ++c) {
+        g.hFactor[c] = g.stepW / g.wf[c] / 8;                 // SamplingScheme.h:39-42
+        g.vFactor[c] = g.stepH / g.hf[c] / 8;
+        if (g.hFactor[c] > 4 || g.vFactor[c] > 4) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+        g.chanOffset[c] = g.blocksPerMcu;
+        g.chanBlocks[c] = g.hFactor[c] * g.vFactor[c];
+        g.blocksPerMcu += g.chanBlocks[c];
+    }
+    int r0 = p.mcu_row_begin, r1 = p.mcu_row_end;
+    if (r0 == 0 && r1 == 0) r1 = g.mcuRows;
+    if (r0 < 0 || r1 > g.mcuRows || r0 >= r1) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    g.bandRow0 = r0;
+    g.bandRows = r1 - r0;
+    g.startsImage = r0 == 0;
+    g.endsImage = r1 == g.mcuRows;
+    g.nMcu = (int64_t)g.bandRows * g.mcusPerRow;
+    g.totalBlocks = g.nMcu * g.blocksPerMcu;
+    g.restartInterval = p.restart_interval;
+    if (g.restartInterval > 0) {
+        const int64_t firstMcu = (int64_t)r0 * g.mcusPerRow;
+        if (firstMcu % g.restartInterval != 0) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+        g.firstInterval = firstMcu / g.restartInterval;
+        g.intervals = (g.nMcu + g.restartInterval - 1) / g.restartInterval;
+    } else {
+        if (!g.startsImage || !g.endsImage) return JPEG_HIP_ERR_INVALID_ARGUMENT;   // bands need restart markers
+        g.firstInterval = 0;
+        g.intervals = 1;
+    }
+    return JPEG_HIP_OK;
+}
+
+}  // namespace jpeghip
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        // Grow with headroom so a stream of slightly different images does not reallocate.
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Pinned {
+    uint64_t hist[4 * 256];
+    uint32_t tables[4 * 256];
+    uint64_t result[4];
+    uint8_t header[2048];
+};
+
+}  // namespace
+
+struct jpeg_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err = "";
+    jpeg_hip_params prm;
+    Geometry geo;
+    KGeom kg;
+    bool begun = false, hasPixels = false, transformed = false, hasTables = false;
+    const void* rgb = nullptr;
+    int fmt = JPEG_HIP_RGB8;
+    int64_t stride = 0;
+    DevBuf pixels, coef, qtab, hist, tables, bitLen, bitOff, ivBytes, ivOff, ffCount, ffOff, scanTmp, result, unstuffed,
+        staging;
+    EntropyWorkspace ws;
+    Pinned* pin = nullptr;
+    uint8_t lengths[4][256];
+    uint16_t codes[4][256];
+    bool profiling = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float times[4] = {0, 0, 0, 0};
+};
+
+namespace {
+
+int fail(jpeg_hip_ctx* ctx, int status, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return status;
+}
+
+int hip_fail(jpeg_hip_ctx* ctx, hipError_t e, const char* what) {
+    return fail(ctx, JPEG_HIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, call)                                      \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call);  \
+    } while (0)
+
+int bytes_per_sample(int fmt) { return fmt == JPEG_HIP_RGBF32 ? 4 : 1; }
+
+int check_pixels(jpeg_hip_ctx* ctx, const void* p, int fmt, int64_t stride) {
+    if (!p) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "pixel pointer is null");
+    if (fmt != JPEG_HIP_RGB8 && fmt != JPEG_HIP_RGBF32) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "unknown sample format");
+    if (stride < (int64_t)ctx->geo.width * 3 * bytes_per_sample(fmt))
+        return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "row stride is smaller than one row of pixels");
+    if (fmt == JPEG_HIP_RGBF32 && (stride % 4 != 0 || ((uintptr_t)p & 3) != 0))
+        return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "float pixels must be 4-byte aligned");
+    return JPEG_HIP_OK;
+}
+
+// Real pixel rows reachable from the band's RGB pointer.
+int band_rows_available(const Geometry& g) { return g.height - g.bandRow0 * g.stepH; }
+
+void fill_kgeom(jpeg_hip_ctx* ctx) {
+    const Geometry& g = ctx->geo;
+    KGeom& k = ctx->kg;
+    k.W = g.width;
+    k.rowsAvail = band_rows_available(g);
+    k.strideBytes = ctx->stride;
+    k.sampleFormat = ctx->fmt;
+    k.stages = JPEG_HIP_STAGE_ALL;
+    k.mcusPerRow = g.mcusPerRow;
+    k.nMcu = g.nMcu;
+    k.totalBlocks = g.totalBlocks;
+    k.bpm = g.blocksPerMcu;
+    k.off1 = g.chanOffset[1];
+    k.off2 = g.chanOffset[2];
+    for (int c = 0; c < 3; ++c) {
+        k.hF[c] = g.hFactor[c];
+        k.vF[c] = g.vFactor[c];
+        k.wf[c] = g.wf[c];
+        k.wm[c] = g.wm[c];
+        k.hf[c] = g.hf[c];
+        k.hm[c] = g.hm[c];
+    }
+    k.mcusPerInterval = g.restartInterval > 0 ? g.restartInterval : g.nMcu;
+    k.intervals = g.intervals;
+    k.firstInterval = g.firstInterval;
+    k.padOnes = ctx->prm.pad_ones ? 1 : 0;
+}
+
+int ensure_workspace(jpeg_hip_ctx* ctx) {
+    const Geometry& g = ctx->geo;
+    const int64_t nb = g.totalBlocks;
+    const int64_t unstuffedCap = (worst_case_scan_bytes(nb) + kStuffChunk + 63) / 16 * 16;
+    const int64_t maxChunks = (unstuffedCap + kStuffChunk - 1) / kStuffChunk;
+    int64_t scanItems = nb > maxChunks ? nb : maxChunks;
+    if (g.intervals > scanItems) scanItems = g.intervals;
+    HIP_TRY(ctx, ctx->coef.ensure((size_t)nb * 128));
+    HIP_TRY(ctx, ctx->qtab.ensure(3 * 64 * sizeof(float)));
+    HIP_TRY(ctx, ctx->hist.ensure(1024 * sizeof(uint64_t)));
+    HIP_TRY(ctx, ctx->tables.ensure(1024 * sizeof(uint32_t)));
+    HIP_TRY(ctx, ctx->bitLen.ensure((size_t)nb * 4));
+    HIP_TRY(ctx, ctx->bitOff.ensure((size_t)(nb + 1) * 8));
+    HIP_TRY(ctx, ctx->ivBytes.ensure((size_t)g.intervals * 8));
+    HIP_TRY(ctx, ctx->ivOff.ensure((size_t)(g.intervals + 1) * 8));
+    HIP_TRY(ctx, ctx->ffCount.ensure((size_t)maxChunks * 4));
+    HIP_TRY(ctx, ctx->ffOff.ensure((size_t)(maxChunks + 1) * 8));
+    HIP_TRY(ctx, ctx->scanTmp.ensure((size_t)(scanItems / 2048 + 2) * 8));
+    HIP_TRY(ctx, ctx->result.ensure(4 * 8));
+    HIP_TRY(ctx, ctx->unstuffed.ensure((size_t)unstuffedCap));
+    EntropyWorkspace& ws = ctx->ws;
+    ws.bitLen = (uint32_t*)ctx->bitLen.p;
+    ws.bitOff = (unsigned long long*)ctx->bitOff.p;
+    ws.ivBytes = (unsigned long long*)ctx->ivBytes.p;
+    ws.ivOff = (unsigned long long*)ctx->ivOff.p;
+    ws.ffCount = (uint32_t*)ctx->ffCount.p;
+    ws.ffOff = (unsigned long long*)ctx->ffOff.p;
+    ws.scanTmp = (unsigned long long*)ctx->scanTmp.p;
+    ws.result = (unsigned long long*)ctx->result.p;
+    ws.unstuffed = (uint8_t*)ctx->unstuffed.p;
+    ws.unstuffedCap = unstuffedCap;
+    ws.maxChunks = maxChunks;
+    return JPEG_HIP_OK;
+}
+
+void mark(jpeg_hip_ctx* ctx, int i) {
+    if (ctx->profiling) (void)hipEventRecord(ctx->ev[i], ctx->stream);
+}
+
+int install_tables(jpeg_hip_ctx* ctx) {
+    for (int t = 0; t < 4; ++t)
+        for (int s = 0; s < 256; ++s)
+            ctx->pin->tables[t * 256 + s] = ((uint32_t)ctx->lengths[t][s] << 16) | ctx->codes[t][s];
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->pin->tables, sizeof ctx->pin->tables, hipMemcpyHostToDevice,
+                                ctx->stream));
+    ctx->hasTables = true;
+    return JPEG_HIP_OK;
+}
+
+int build_tables(jpeg_hip_ctx* ctx, const uint64_t* hist) {
+    auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < 4; ++t) {
+        uint64_t total = 0;
+        for (int s = 0; s < 256; ++s) total += hist[t * 256 + s];
+        if (total == 0) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "a symbol histogram is empty");
+        huffman_from_histogram(hist + t * 256, ctx->lengths[t], ctx->codes[t]);
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    ctx->times[3] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    return install_tables(ctx);
+}
+
+// Runs the entropy kernels and reads the length back.  prefix: bytes already placed at
+// the start of d_out (headers).
+int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capacity, int writeEoi, int64_t* outLen) {
+    mark(ctx, 3);
+    HIP_TRY(ctx, launch_entropy(ctx->kg, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, d_out,
+                                prefix, capacity, writeEoi, ctx->stream));
+    mark(ctx, 4);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin->result, ctx->result.p, sizeof ctx->pin->result, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->times[0] = ms;
+        if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->times[1] = ms;
+        if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->times[2] = ms;
+    }
+    if (ctx->pin->result[1] != 0) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "output buffer is too small for the scan");
+    *outLen = (int64_t)ctx->pin->result[0];
+    return JPEG_HIP_OK;
+}
+
+int do_transform(jpeg_hip_ctx* ctx, int stages) {
+    if (!ctx->begun || !ctx->hasPixels) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "transform needs begin() and pixels");
+    const Geometry& g = ctx->geo;
+    const bool subsampled = g.blocksPerMcu != 3;
+    if (subsampled && !(stages & JPEG_HIP_STAGE_SUBSAMPLE))
+        return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "a subsampled scheme needs the subsample stage");
+    fill_kgeom(ctx);
+    ctx->kg.stages = stages;
+    mark(ctx, 0);
+    HIP_TRY(ctx, launch_transform(ctx->kg, ctx->rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, ctx->stream));
+    mark(ctx, 1);
+    ctx->transformed = true;
+    return JPEG_HIP_OK;
+}
+
+int do_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist) {
+    if (!ctx->transformed) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "histograms need the transform");
+    HIP_TRY(ctx, launch_histogram(ctx->kg, (const int16_t*)ctx->coef.p, (unsigned long long*)d_hist, ctx->stream));
+    mark(ctx, 2);
+    return JPEG_HIP_OK;
+}
+
+int fetch_hist_and_build(jpeg_hip_ctx* ctx, const uint64_t* d_hist) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin->hist, d_hist, sizeof ctx->pin->hist, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return build_tables(ctx, ctx->pin->hist);
+}
+
+// Headers (when the band starts the image) go to the front of d_out; returns their length.
+int place_headers(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t capacity, int64_t* prefix) {
+    *prefix = 0;
+    if (!ctx->geo.startsImage) return JPEG_HIP_OK;
+    const int n = write_headers(ctx->prm, ctx->geo, ctx->lengths, ctx->codes, ctx->pin->header, (int)sizeof ctx->pin->header);
+    if (n < 0) return fail(ctx, n, "header assembly failed");
+    if (n > capacity) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "output buffer is too small for the headers");
+    HIP_TRY(ctx, hipMemcpyAsync(d_out, ctx->pin->header, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    *prefix = n;
+    return JPEG_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* jpeg_hip_status_string(int status) {
+    switch (status) {
+        case JPEG_HIP_OK: return "ok";
+        case JPEG_HIP_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case JPEG_HIP_ERR_HIP: return "HIP runtime error";
+        case JPEG_HIP_ERR_BUFFER_TOO_SMALL: return "buffer too small";
+        case JPEG_HIP_ERR_BAD_STATE: return "entry points called out of order";
+        case JPEG_HIP_ERR_NO_DEVICE: return "no usable GPU";
+        default: return "unknown status";
+    }
+}
+
+int jpeg_hip_create(int device_id, jpeg_hip_ctx** out_ctx) {
+    if (!out_ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return JPEG_HIP_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= count) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(device_id) != hipSuccess) return JPEG_HIP_ERR_HIP;
+    jpeg_hip_ctx* ctx = new (std::nothrow) jpeg_hip_ctx();
+    if (!ctx) return JPEG_HIP_ERR_HIP;
+    ctx->device = device_id;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void**)&ctx->pin, sizeof(Pinned), hipHostMallocDefault) != hipSuccess) {
+        jpeg_hip_destroy(ctx);
+        return JPEG_HIP_ERR_HIP;
+    }
+    for (auto& e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            jpeg_hip_destroy(ctx);
+            return JPEG_HIP_ERR_HIP;
+        }
+    *out_ctx = ctx;
+    return JPEG_HIP_OK;
+}
+
+void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->bitLen, &ctx->bitOff,
+                      &ctx->ivBytes, &ctx->ivOff, &ctx->ffCount, &ctx->ffOff, &ctx->scanTmp, &ctx->result,
+                      &ctx->unstuffed, &ctx->staging};
+    for (DevBuf* b : bufs) b->release();
+    for (auto& e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* jpeg_hip_last_error(const jpeg_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+void* jpeg_hip_stream(jpeg_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int jpeg_hip_compute_layout(const jpeg_hip_params* params, jpeg_hip_layout* out) {
+    if (!params || !out) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    Geometry g;
+    const int st = make_geometry(*params, g);
+    if (st != JPEG_HIP_OK) return st;
+    out->padded_width = g.simW;
+    out->padded_height = g.simH;
+    out->mcu_width = g.stepW;
+    out->mcu_height = g.stepH;
+    out->mcus_per_row = g.mcusPerRow;
+    out->mcu_rows = g.mcuRows;
+    out->band_mcu_rows = g.bandRows;
+    out->blocks_per_mcu = g.blocksPerMcu;
+    out->total_blocks = g.totalBlocks;
+    for (int c = 0; c < 3; ++c) {
+        out->h_factor[c] = g.hFactor[c];
+        out->v_factor[c] = g.vFactor[c];
+        out->blocks[c] = g.nMcu * g.chanBlocks[c];
+    }
+    out->intervals = g.intervals;
+    // Headers, every scan byte stuffed, one marker per interval, EOI.
+    out->max_jpeg_bytes = 2048 + 2 * worst_case_scan_bytes(g.totalBlocks) + 2 * g.intervals + 2;
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_begin(jpeg_hip_ctx* ctx, const jpeg_hip_params* params) {
+    if (!ctx || !params) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Geometry g;
+    const int st = make_geometry(*params, g);
+    if (st != JPEG_HIP_OK) return fail(ctx, st, "invalid image parameters");
+    ctx->prm = *params;
+    ctx->geo = g;
+    ctx->begun = true;
+    ctx->hasPixels = ctx->transformed = ctx->hasTables = false;
+    const int ws = ensure_workspace(ctx);
+    if (ws != JPEG_HIP_OK) return ws;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->qtab.p, params->qtable, 3 * 64 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    // The parameter block is caller memory: finish the copy before returning.
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_bind_pixels(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes) {
+    if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
+    const int st = check_pixels(ctx, d_rgb, sample_format, stride_bytes);
+    if (st != JPEG_HIP_OK) return st;
+    ctx->rgb = d_rgb;
+    ctx->fmt = sample_format;
+    ctx->stride = stride_bytes;
+    ctx->hasPixels = true;
+    ctx->transformed = false;
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_upload_pixels(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format, int64_t stride_bytes) {
+    if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
+    const int st = check_pixels(ctx, h_rgb, sample_format, stride_bytes);
+    if (st != JPEG_HIP_OK) return st;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rows = std::min(band_rows_available(ctx->geo), ctx->geo.bandRows * ctx->geo.stepH);
+    const size_t rowBytes = (size_t)ctx->geo.width * 3 * bytes_per_sample(sample_format);
+    const size_t dstStride = (rowBytes + 3) / 4 * 4;
+    HIP_TRY(ctx, ctx->pixels.ensure(dstStride * rows));
+    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->pixels.p, dstStride, h_rgb, (size_t)stride_bytes, rowBytes, (size_t)rows,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->rgb = ctx->pixels.p;
+    ctx->fmt = sample_format;
+    ctx->stride = (int64_t)dstStride;
+    ctx->hasPixels = true;
+    ctx->transformed = false;
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_transform(jpeg_hip_ctx* ctx, int stages) {
+    if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return do_transform(ctx, stages);
+}
+
+int jpeg_hip_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist) {
+    if (!ctx || !d_hist) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return do_histograms(ctx, d_hist);
+}
+
+int jpeg_hip_histograms_host(jpeg_hip_ctx* ctx, uint64_t* h_hist) {
+    if (!ctx || !h_hist) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int st = do_histograms(ctx, (uint64_t*)ctx->hist.p);
+    if (st != JPEG_HIP_OK) return st;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin->hist, ctx->hist.p, sizeof ctx->pin->hist, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(h_hist, ctx->pin->hist, sizeof ctx->pin->hist);
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_huffman_from_histogram(const uint64_t counts[256], uint8_t lengths[256], uint16_t codes[256]) {
+    if (!counts || !lengths || !codes) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    huffman_from_histogram(counts, lengths, codes);
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_write_dht(const uint8_t lengths[256], const uint16_t codes[256], int table_id, int coefficient_type,
+                       uint8_t* h_out, int capacity) {
+    if (!lengths || !codes || !h_out) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    return write_dht(lengths, codes, table_id, coefficient_type, h_out, capacity);
+}
+
+int jpeg_hip_write_headers(const jpeg_hip_params* params, const uint8_t lengths[4][256], const uint16_t codes[4][256],
+                           uint8_t* h_out, int capacity) {
+    if (!params || !lengths || !codes || !h_out) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    Geometry g;
+    const int st = make_geometry(*params, g);
+    if (st != JPEG_HIP_OK) return st;
+    return write_headers(*params, g, lengths, codes, h_out, capacity);
+}
+
+int jpeg_hip_set_huffman(jpeg_hip_ctx* ctx, const uint8_t lengths[4][256], const uint16_t codes[4][256]) {
+    if (!ctx || !lengths || !codes) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    memcpy(ctx->lengths, lengths, sizeof ctx->lengths);
+    memcpy(ctx->codes, codes, sizeof ctx->codes);
+    return install_tables(ctx);
+}
+
+int jpeg_hip_build_huffman(jpeg_hip_ctx* ctx, const uint64_t h_hist[4][256]) {
+    if (!ctx || !h_hist) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return build_tables(ctx, &h_hist[0][0]);
+}
+
+int jpeg_hip_get_huffman(jpeg_hip_ctx* ctx, uint8_t lengths[4][256], uint16_t codes[4][256]) {
+    if (!ctx || !lengths || !codes) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->hasTables) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "no Huffman tables installed");
+    memcpy(lengths, ctx->lengths, sizeof ctx->lengths);
+    memcpy(codes, ctx->codes, sizeof ctx->codes);
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_emit_scan(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t out_capacity, int64_t* out_len) {
+    if (!ctx || !d_out || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->transformed || !ctx->hasTables) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "emit needs coefficients and tables");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return run_entropy(ctx, d_out, 0, out_capacity, 0, out_len);
+}
+
+int jpeg_hip_get_coefficients(jpeg_hip_ctx* ctx, int channel, int16_t* h_out, int64_t capacity_values) {
+    if (!ctx || !h_out || channel < 0 || channel > 2) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->transformed) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "no coefficients yet");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const Geometry& g = ctx->geo;
+    const int64_t perMcu = g.chanBlocks[channel];
+    if (capacity_values < g.nMcu * perMcu * 64) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "coefficient buffer too small");
+    // Scan order interleaves the channels per MCU; copy this channel's slices out.
+    HIP_TRY(ctx, hipMemcpy2DAsync(h_out, (size_t)perMcu * 128, (const char*)ctx->coef.p + (size_t)g.chanOffset[channel] * 128,
+                                  (size_t)g.blocksPerMcu * 128, (size_t)perMcu * 128, (size_t)g.nMcu,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_HIP_OK;
+}
+
+const int16_t* jpeg_hip_coefficients_device(jpeg_hip_ctx* ctx) {
+    return ctx && ctx->transformed ? (const int16_t*)ctx->coef.p : nullptr;
+}
+
+int jpeg_hip_analyze_band(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
+                          const jpeg_hip_params* params, uint64_t* d_hist) {
+    if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    int st = jpeg_hip_begin(ctx, params);
+    if (st != JPEG_HIP_OK) return st;
+    st = jpeg_hip_bind_pixels(ctx, d_rgb, sample_format, stride_bytes);
+    if (st != JPEG_HIP_OK) return st;
+    st = do_transform(ctx, JPEG_HIP_STAGE_ALL);
+    if (st != JPEG_HIP_OK) return st;
+    // A null d_hist keeps the histograms in the context's own buffer.
+    return do_histograms(ctx, d_hist ? d_hist : (uint64_t*)ctx->hist.p);
+}
+
+int jpeg_hip_finish_band(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t* d_out, int64_t out_capacity,
+                         int64_t* out_len) {
+    if (!ctx || !d_hist_sum || !d_out || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->transformed) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "finish needs analyze");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int st = fetch_hist_and_build(ctx, d_hist_sum);
+    if (st != JPEG_HIP_OK) return st;
+    int64_t prefix = 0;
+    st = place_headers(ctx, d_out, out_capacity, &prefix);
+    if (st != JPEG_HIP_OK) return st;
+    return run_entropy(ctx, d_out, prefix, out_capacity, ctx->geo.endsImage ? 1 : 0, out_len);
+}
+
+int jpeg_hip_encode(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
+                    const jpeg_hip_params* params, uint8_t* d_out, int64_t out_capacity, int64_t* out_len) {
+    if (!ctx || !d_out || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    int st = jpeg_hip_analyze_band(ctx, d_rgb, sample_format, stride_bytes, params, nullptr);
+    if (st != JPEG_HIP_OK) return st;
+    return jpeg_hip_finish_band(ctx, (const uint64_t*)ctx->hist.p, d_out, out_capacity, out_len);
+}
+
+int jpeg_hip_encode_host(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format, int64_t stride_bytes,
+                         const jpeg_hip_params* params, uint8_t* h_out, int64_t out_capacity, int64_t* out_len) {
+    if (!ctx || !h_out || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    int st = jpeg_hip_begin(ctx, params);
+    if (st != JPEG_HIP_OK) return st;
+    st = jpeg_hip_upload_pixels(ctx, h_rgb, sample_format, stride_bytes);
+    if (st != JPEG_HIP_OK) return st;
+    st = do_transform(ctx, JPEG_HIP_STAGE_ALL);
+    if (st != JPEG_HIP_OK) return st;
+    st = do_histograms(ctx, (uint64_t*)ctx->hist.p);
+    if (st != JPEG_HIP_OK) return st;
+    jpeg_hip_layout lay;
+    st = jpeg_hip_compute_layout(params, &lay);
+    if (st != JPEG_HIP_OK) return st;
+    HIP_TRY(ctx, ctx->staging.ensure((size_t)lay.max_jpeg_bytes));
+    int64_t len = 0;
+    st = jpeg_hip_finish_band(ctx, (const uint64_t*)ctx->hist.p, (uint8_t*)ctx->staging.p, lay.max_jpeg_bytes, &len);
+    if (st != JPEG_HIP_OK) return st;
+    if (len > out_capacity) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "host output buffer too small");
+    HIP_TRY(ctx, hipMemcpyAsync(h_out, ctx->staging.p, (size_t)len, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out_len = len;
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_set_profiling(jpeg_hip_ctx* ctx, int enabled) {
+    if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    ctx->profiling = enabled != 0;
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_get_timings(jpeg_hip_ctx* ctx, float out_ms[4]) {
+    if (!ctx || !out_ms) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    memcpy(out_ms, ctx->times, sizeof ctx->times);
+    return JPEG_HIP_OK;
+}
+
+}  // extern "C"

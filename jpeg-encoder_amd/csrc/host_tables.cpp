@@ -1,0 +1,159 @@
+// Host side of the entropy stage: length-limited Huffman tables from symbol histograms
+// and the JFIF header segments.  No GPU code in this file.
+//
+// The reference builds its tables with a package-merge pass over shared_ptr trees
+// (HuffmanCodingByte.h:102-210) and breaks frequency ties through libstdc++'s unstable
+// std::sort, so byte-identical DHT segments need the same sort calls on sequences of the
+// same length and initial order.  This implementation keeps those calls but works on a
+// flat node pool and derives the code lengths by pushing selection counts from parents to
+// children instead of walking every selected tree.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "internal.h"
+
+namespace jpeghip {
+
+namespace {
+
+const int kZigZagOrder[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+}  // namespace
+
+const int* zigzag_order() { return kZigZagOrder; }
+
+void huffman_from_histogram(const uint64_t counts[256], uint8_t lengths[256], uint16_t codes[256]) {
+    memset(lengths, 0, 256);
+    memset(codes, 0, 512);
+
+    // Leaves in ascending symbol order, then the zero-frequency dummy that keeps the
+    // all-ones code unused (HuffmanCodingByte.h:124-135).
+    int leafSymbol[257];
+    int nLeaves = 0;
+    for (int s = 0; s < 256; ++s)
+        if (counts[s] != 0) leafSymbol[nLeaves++] = s;
+    if (nLeaves == 0) return;  // empty table, HuffmanCodingByte.h:110
+    const int dummy = nLeaves;
+    leafSymbol[nLeaves++] = 0;
+
+    const int kMaxLen = 16;
+    // Pool: leaves first, then every package in creation order, so a package's children
+    // always sit at lower indices than the package itself.
+    std::vector<uint64_t> freq;
+    std::vector<int> lhs, rhs;
+    freq.reserve(nLeaves * kMaxLen);
+    lhs.reserve(nLeaves * kMaxLen);
+    rhs.reserve(nLeaves * kMaxLen);
+    for (int i = 0; i < nLeaves; ++i) {
+        freq.push_back(i == dummy ? 0 : counts[leafSymbol[i]]);
+        lhs.push_back(-1);
+        rhs.push_back(-1);
+    }
+    auto lessFreq = [&freq](int a, int b) { return freq[a] < freq[b]; };
+
+    std::vector<int> level(nLeaves), next;
+    for (int i = 0; i < nLeaves; ++i) level[i] = i;
+    for (int round = 1; round < kMaxLen; ++round) {  // HuffmanCodingByte.h:139-156
+        std::sort(level.begin(), level.end(), lessFreq);
+        next.resize(nLeaves);
+        for (int i = 0; i < nLeaves; ++i) next[i] = i;
+        for (size_t i = 1; i < level.size(); i += 2) {
+            next.push_back((int)freq.size());
+            freq.push_back(freq[level[i - 1]] + freq[level[i]]);
+            lhs.push_back(level[i - 1]);
+            rhs.push_back(level[i]);
+        }
+        level.swap(next);
+    }
+    std::sort(level.begin(), level.end(), lessFreq);  // HuffmanCodingByte.h:159-162
+
+    // The cheapest 2n-2 items each add one to the length of every leaf below them
+    // (HuffmanCodingByte.h:165-168).  Selection counts flow parent -> children.
+    std::vector<uint32_t> weight(freq.size(), 0);
+    for (int i = 0; i < 2 * nLeaves - 2; ++i) weight[level[i]]++;
+    for (int n = (int)freq.size() - 1; n >= nLeaves; --n) {
+        weight[lhs[n]] += weight[n];
+        weight[rhs[n]] += weight[n];
+    }
+
+    // Longest code first, ties in std::sort order (HuffmanCodingByte.h:171-178), then
+    // count down from the all-ones word (HuffmanCodingByte.h:181-207).
+    std::vector<int> order(nLeaves);
+    for (int i = 0; i < nLeaves; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&weight](int a, int b) { return weight[a] > weight[b]; });
+    uint32_t lastLen = weight[order[0]];
+    uint64_t code = ~uint64_t(0) >> (64 - lastLen);
+    for (int i = 0; i < nLeaves; ++i) {
+        const int leaf = order[i];
+        if (leaf == dummy) continue;  // the only zero-frequency leaf
+        const uint32_t len = weight[leaf];
+        if (len != lastLen) code >>= (lastLen - len);
+        --code;
+        lengths[leafSymbol[leaf]] = (uint8_t)len;
+        codes[leafSymbol[leaf]] = (uint16_t)code;
+        lastLen = len;
+    }
+}
+
+int write_dht(const uint8_t lengths[256], const uint16_t codes[256], int tableId, int coefType, uint8_t* out,
+              int capacity) {
+    // Symbols ordered by (length, code), JPEGSegments.h:117-129.
+    int syms[256];
+    int n = 0;
+    for (int s = 0; s < 256; ++s)
+        if (lengths[s] != 0) syms[n++] = s;
+    if (n == 0) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    std::sort(syms, syms + n, [&](int a, int b) {
+        return lengths[a] != lengths[b] ? lengths[a] < lengths[b] : codes[a] < codes[b];
+    });
+    const int total = 2 + 2 + 1 + 16 + n;
+    if (capacity < total) return JPEG_HIP_ERR_BUFFER_TOO_SMALL;
+    uint8_t* p = out;
+    *p++ = 0xff;
+    *p++ = 0xc4;
+    const int segLen = total - 2;
+    *p++ = (uint8_t)(segLen >> 8);
+    *p++ = (uint8_t)segLen;
+    *p++ = (uint8_t)((tableId & 15) | ((coefType & 1) << 4));
+    memset(p, 0, 16);
+    for (int i = 0; i < n; ++i) p[lengths[syms[i]] - 1]++;
+    p += 16;
+    for (int i = 0; i < n; ++i) *p++ = (uint8_t)syms[i];
+    return total;
+}
+
+int write_headers(const jpeg_hip_params& prm, const Geometry& g, const uint8_t lengths[4][256],
+                  const uint16_t codes[4][256], uint8_t* out, int capacity) {
+    std::vector<uint8_t> h;
+    h.reserve(1024);
+    auto put = [&h](std::initializer_list<int> bytes) {
+        for (int b : bytes) h.push_back((uint8_t)b);
+    };
+    put({0xff, 0xd8});                                                                  // SOI, JPEGSegments.h:50-54
+    put({0xff, 0xe0, 0x00, 0x10, 'J', 'F', 'I', 'F', 0x00, 0x01, 0x01, 0x00, 0x00, 0x48, 0x00, 0x48, 0x00, 0x00});  // :62-75
+    put({0xff, 0xc0, 0x00, 0x11, 0x08, (prm.height >> 8) & 255, prm.height & 255, (prm.width >> 8) & 255,
+         prm.width & 255, 0x03});                                                        // SOF0, :77-100
+    for (int c = 0; c < 3; ++c) put({c + 1, (g.hFactor[c] << 4) | (g.vFactor[c] & 15), c});
+    uint8_t seg[2 + 2 + 1 + 16 + 256];
+    const int ids[4] = {0, 1, 0, 1}, types[4] = {JPEG_HIP_DC, JPEG_HIP_DC, JPEG_HIP_AC, JPEG_HIP_AC};  // Encoder.cpp:455-479
+    for (int t = 0; t < 4; ++t) {
+        int n = write_dht(lengths[t], codes[t], ids[t], types[t], seg, (int)sizeof seg);
+        if (n < 0) return n;
+        h.insert(h.end(), seg, seg + n);
+    }
+    for (int c = 0; c < 3; ++c) {                                                        // DQT, :152-167
+        put({0xff, 0xdb, 0x00, 0x43, c});
+        for (int i = 0; i < 64; ++i) h.push_back((uint8_t)prm.qtable[c][kZigZagOrder[i]]);
+    }
+    if (prm.restart_interval > 0)
+        put({0xff, 0xdd, 0x00, 0x04, (prm.restart_interval >> 8) & 255, prm.restart_interval & 255});
+    put({0xff, 0xda, 0x00, 0x0c, 0x03, 0x01, 0x00, 0x02, 0x11, 0x03, 0x11, 0x00, 0x3f, 0x00});  // SOS, :175-190
+    if ((int)h.size() > capacity) return JPEG_HIP_ERR_BUFFER_TOO_SMALL;
+    memcpy(out, h.data(), h.size());
+    return (int)h.size();
+}
+
+}  // namespace jpeghip

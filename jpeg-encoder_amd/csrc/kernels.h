@@ -1,0 +1,63 @@
+// Launch interface between the host C ABI and the device kernels of libjpegenc_hip.
+#ifndef JPEGHIP_KERNELS_H
+#define JPEGHIP_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace jpeghip {
+
+// Everything the kernels need to know about the band being encoded, passed by value.
+struct KGeom {
+    int W;                   // real image width in pixels
+    int rowsAvail;           // real pixel rows reachable from the RGB pointer
+    long long strideBytes;   // RGB row stride
+    int sampleFormat;        // JPEG_HIP_RGB8 / JPEG_HIP_RGBF32
+    int stages;              // JPEG_HIP_STAGE_* bits
+    int mcusPerRow;
+    long long nMcu;          // MCUs in the band
+    long long totalBlocks;
+    int bpm;                 // blocks per MCU
+    int off1, off2;          // first Cb / Cr block inside an MCU
+    int hF[3], vF[3];        // blocks per MCU across / down, per channel
+    int wf[3], wm[3], hf[3], hm[3];
+    long long mcusPerInterval;   // restart interval, or nMcu when restarts are off
+    long long intervals;
+    long long firstInterval;     // global index of the band's first interval
+    int padOnes;
+};
+
+// Device workspace of the entropy stage (all sizes fixed by the geometry).
+struct EntropyWorkspace {
+    uint32_t* bitLen;            // [totalBlocks]
+    unsigned long long* bitOff;  // [totalBlocks + 1]
+    unsigned long long* ivBytes; // [intervals]
+    unsigned long long* ivOff;   // [intervals + 1]
+    uint32_t* ffCount;           // [maxChunks]
+    unsigned long long* ffOff;   // [maxChunks + 1]
+    unsigned long long* scanTmp; // scratch for the scans
+    unsigned long long* result;  // [4]: stuffed length, overflow flag, unstuffed bytes, 0xFF count
+    uint8_t* unstuffed;          // [unstuffedCap]
+    long long unstuffedCap;
+    long long maxChunks;
+};
+
+constexpr int kStuffChunk = 4096;   // unstuffed bytes handled by one workgroup pass
+
+// Fused colour conversion + subsampling + DCT + quantization + zig-zag.
+hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef, hipStream_t s);
+
+// Symbol histograms (uint64[4][256]); d_hist is cleared first.
+hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, unsigned long long* d_hist, hipStream_t s);
+
+// Bit lengths, offsets, bit writer and byte stuffing.  d_tables: uint32[4][256], entry =
+// (length << 16) | code.  Scan bytes go to d_out + prefixLen; EOI is appended when
+// writeEoi is set.  ws.result[0] receives prefixLen + scan bytes (+ 2 with EOI);
+// ws.result[1] is non-zero when outCapacity was too small.
+hipError_t launch_entropy(const KGeom& g, const int16_t* d_coef, const uint32_t* d_tables, const EntropyWorkspace& ws,
+                          uint8_t* d_out, long long prefixLen, long long outCapacity, int writeEoi, hipStream_t s);
+
+}  // namespace jpeghip
+
+#endif

@@ -1,0 +1,690 @@
+// Device kernels of the MI355X (gfx950) JPEG encode hot path.
+//
+// Build with -ffp-contract=off: the transform must round every multiply and add on its
+// own, exactly like the reference's AVX path (SIMD256.h:155-186, 337-441).  Division is
+// the compiler's correctly rounded fp32 division, rounding is v_rndne_f32 (ties to even).
+#include "kernels.h"
+
+#include "jpegenc_hip.h"
+
+namespace jpeghip {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// ZigZag.h:10-19
+__device__ constexpr int kZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// AAN factors exactly as the reference's constexpr cosine recursion yields them
+// (const_math.h:16-41, SIMD256.h:335-352); several differ from cosf() by 1-2 ulp.
+#define AAN_A1 0x1.6a09e6p-1f
+#define AAN_A2 0x1.1517a8p-1f
+#define AAN_A4 0x1.4e7aeap+0f
+#define AAN_A5 0x1.87de2cp-2f
+#define AAN_S0 0x1.6a09e6p-2f
+#define AAN_S1 0x1.0503ecp-2f
+#define AAN_S2 0x1.1517a8p-2f
+#define AAN_S3 0x1.33e37ap-2f
+#define AAN_S4 0x1.6a09e6p-2f
+#define AAN_S5 0x1.ccc9aep-2f
+#define AAN_S6 0x1.4e7ae8p-1f
+#define AAN_S7 0x1.480da4p+0f
+
+// One 8-point AAN pass, operation order of SIMD256.h:354-415.
+__device__ __forceinline__ void aan1d(float& x0, float& x1, float& x2, float& x3, float& x4, float& x5, float& x6,
+                                      float& x7) {
+    const float t0 = x0 + x7, t1 = x1 + x6, t2 = x2 + x5, t3 = x3 + x4;
+    const float t4 = x3 - x4, t5 = x2 - x5, t6 = x1 - x6, t7 = x0 - x7;
+    const float r0 = t0 + t3, r1 = t1 + t2, r2 = t1 - t2, r3 = t0 - t3;
+    const float r4 = t4 + t5, r5 = t5 + t6, r6 = t6 + t7, r7 = t7;
+    const float u0 = r0 + r1, u1 = r0 - r1;
+    float u2 = r2 + r3;
+    const float z = r6 - r4;
+    u2 = u2 * AAN_A1;
+    const float za5 = z * AAN_A5;
+    const float u4 = (r4 * AAN_A2) - za5;
+    const float u5m = r5 * AAN_A1;
+    const float u6 = (r6 * AAN_A4) - za5;
+    const float y2 = u2 + r3, y6 = r3 - u2;
+    const float u5 = u5m + r7, u7 = r7 - u5m;
+    x0 = u0 * AAN_S0;
+    x4 = u1 * AAN_S4;
+    x2 = y2 * AAN_S2;
+    x6 = y6 * AAN_S6;
+    x5 = (u4 + u7) * AAN_S5;
+    x1 = (u5 + u6) * AAN_S1;
+    x7 = (u5 - u6) * AAN_S7;
+    x3 = (u7 - u4) * AAN_S3;
+}
+
+// Rows, then columns, then DC - 1024 (SIMD256.h:426-441).  v is row-major.
+__device__ __forceinline__ void aan2d(float (&v)[64]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        aan1d(v[8 * r], v[8 * r + 1], v[8 * r + 2], v[8 * r + 3], v[8 * r + 4], v[8 * r + 5], v[8 * r + 6], v[8 * r + 7]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) aan1d(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
+    v[0] = v[0] - 1024.0f;
+}
+
+// One colour channel of one pixel (SIMD256.h:155-186).  The reference also adds the
+// matrix's "0 * 1" term; adding +0.0f can only turn a -0.0 into +0.0, which no later
+// step can observe in the integer coefficients, so it is left out.
+__device__ __forceinline__ float channel_value(int c, bool convert, float r, float g, float b) {
+    if (!convert) return c == 0 ? r : (c == 1 ? g : b);
+    const float m0 = c == 0 ? 0.2990f : (c == 1 ? -0.1687f : 0.5000f);
+    const float m1 = c == 0 ? 0.5870f : (c == 1 ? -0.3312f : -0.4186f);
+    const float m2 = c == 0 ? 0.1140f : (c == 1 ? 0.5000f : -0.0813f);
+    float t = m0 * r;
+    t = t + m1 * g;
+    t = t + m2 * b;
+    if (c != 0) t = t + 0.5f;
+    return t;
+}
+
+__device__ __forceinline__ void load_pixel(const void* rgb, long long stride, int fmt, int x, int y, float& r, float& g,
+                                           float& b) {
+    if (fmt == JPEG_HIP_RGB8) {   // ImageLoader.cpp:190-193: byte / 255.0f
+        const unsigned char* p = (const unsigned char*)rgb + (long long)y * stride + (long long)x * 3;
+        r = (float)p[0] / 255.0f;
+        g = (float)p[1] / 255.0f;
+        b = (float)p[2] / 255.0f;
+    } else {
+        const float* p = (const float*)((const char*)rgb + (long long)y * stride) + (long long)x * 3;
+        r = p[0];
+        g = p[1];
+        b = p[2];
+    }
+}
+
+// Which channel a block of an MCU belongs to, and its position inside the MCU
+// (Encoder::createBlocks, Encoder.cpp:202-223; scan order of Encoder.cpp:500-514).
+__device__ __forceinline__ void block_in_mcu(const KGeom& g, int k, int& c, int& bx, int& by) {
+    c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
+    const int kk = k - (c == 0 ? 0 : (c == 1 ? g.off1 : g.off2));
+    by = kk / g.hF[c];
+    bx = kk - by * g.hF[c];
+}
+
+// ----------------------------------------------------------------------------------------
+// Generic fused transform: any sampling scheme, any image size.  One thread per 8x8
+// block in scan order; samples are gathered (with edge replication, Image.cpp:63-139, and
+// on-the-fly width-then-height reduction, Encoder.cpp:40-155) into LDS, then transformed
+// in registers.
+// ----------------------------------------------------------------------------------------
+constexpr int kGenThreads = 64;
+
+__global__ __launch_bounds__(kGenThreads) void k_transform_generic(KGeom g, const void* __restrict__ rgb,
+                                                                   const float* __restrict__ qtab,
+                                                                   int16_t* __restrict__ coef) {
+    __shared__ float samples[kGenThreads * 65];
+    __shared__ float q[3 * 64];
+    for (int i = threadIdx.x; i < 192; i += kGenThreads) q[i] = qtab[i];
+    __syncthreads();
+
+    const long long b = (long long)blockIdx.x * kGenThreads + threadIdx.x;
+    if (b >= g.totalBlocks) return;
+    const long long m = b / g.bpm;
+    const int k = (int)(b - m * g.bpm);
+    int c, bx, by;
+    block_in_mcu(g, k, c, bx, by);
+    const int my = (int)(m / g.mcusPerRow), mx = (int)(m - (long long)my * g.mcusPerRow);
+    const int X0 = (mx * g.hF[c] + bx) * 8, Y0 = (my * g.vF[c] + by) * 8;
+    const int wf = g.wf[c], hf = g.hf[c];
+    const int nw = g.wm[c] == JPEG_HIP_AVERAGE ? wf : 1;
+    const int nh = g.hm[c] == JPEG_HIP_AVERAGE ? hf : 1;
+    const bool convert = (g.stages & JPEG_HIP_STAGE_YCBCR) != 0;
+    float* mine = samples + threadIdx.x * 65;
+
+    for (int i = 0; i < 64; ++i) {
+        const int sx0 = (X0 + (i & 7)) * wf, sy0 = (Y0 + (i >> 3)) * hf;
+        float vsum = 0.0f, hval = 0.0f;
+        for (int dy = 0; dy < nh; ++dy) {
+            const int sy = min(sy0 + dy, g.rowsAvail - 1);
+            float hsum = 0.0f;
+            for (int dx = 0; dx < nw; ++dx) {
+                const int sx = min(sx0 + dx, g.W - 1);
+                float r, gg, bb;
+                load_pixel(rgb, g.strideBytes, g.sampleFormat, sx, sy, r, gg, bb);
+                const float v = channel_value(c, convert, r, gg, bb);
+                hsum = dx == 0 ? v : hsum + v;
+            }
+            hval = nw > 1 ? hsum / (float)wf : hsum;
+            vsum = dy == 0 ? hval : vsum + hval;
+        }
+        mine[i] = nh > 1 ? vsum / (float)hf : hval;
+    }
+
+    float v[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = mine[i] * 255.0f;   // SIMD256.h:484-494
+    aan2d(v);
+    const float* qc = q + 64 * c;
+    u32 packed[32];
+#pragma unroll
+    for (int z = 0; z < 64; z += 2) {
+        const int lo = (int)rintf(v[kZZ[z]] / qc[kZZ[z]]);
+        const int hi = (int)rintf(v[kZZ[z + 1]] / qc[kZZ[z + 1]]);
+        packed[z >> 1] = ((u32)lo & 0xffffu) | ((u32)hi << 16);
+    }
+    uint4* dst = (uint4*)(coef + b * 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = make_uint4(packed[4 * i], packed[4 * i + 1], packed[4 * i + 2], packed[4 * i + 3]);
+}
+
+hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef, hipStream_t s) {
+    const long long grid = (g.totalBlocks + kGenThreads - 1) / kGenThreads;
+    hipLaunchKernelGGL(k_transform_generic, dim3((unsigned)grid), dim3(kGenThreads), 0, s, g, d_rgb, d_qtab, d_coef);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------------
+// Entropy stage, shared block walk.  A visitor sees the DC symbol, every AC symbol with
+// its amplitude bits, zero-run-length symbols and the end-of-block symbol, in scan order
+// (Encoder::calculateDCValues / calculateACValues, Encoder.cpp:260-352).
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ int bit_category(int v) {   // Encoder::lookupBitCategory, Encoder.cpp:354-366
+    const int a = v < 0 ? -v : v;
+    return 32 - __clz(a);   // __clz(0) == 32
+}
+
+__device__ __forceinline__ int coef_at(const u32 (&w)[32], int i) {
+    return (int)(short)(w[i >> 1] >> ((i & 1) * 16));
+}
+
+// DC predictor of block b: the previous block of the same channel in scan order, 0 at
+// the start of a restart interval (and of the band).
+__device__ __forceinline__ int dc_predictor(const KGeom& g, const int16_t* coef, long long b, long long m, int k,
+                                            int c) {
+    const int first = c == 0 ? 0 : (c == 1 ? g.off1 : g.off2);
+    if (k > first) return coef[(b - 1) * 64];
+    if (m % g.mcusPerInterval == 0) return 0;
+    const int last = (c == 0 ? g.off1 : (c == 1 ? g.off2 : g.bpm)) - 1;
+    return coef[((m - 1) * g.bpm + last) * 64];
+}
+
+template <class Visitor>
+__device__ __forceinline__ void walk_block(const u32 (&w)[32], int pred, Visitor& vis) {
+    const int diff = coef_at(w, 0) - pred;
+    const int dcat = bit_category(diff);
+    vis.dc(dcat, (u32)(diff < 0 ? diff - 1 : diff) & ((1u << dcat) - 1u));
+    int run = 0;
+#pragma unroll
+    for (int i = 1; i < 64; ++i) {
+        const int v = coef_at(w, i);
+        if (v != 0) {
+            if (run > 15) {
+                vis.zrl(run >> 4);
+                run &= 15;
+            }
+            const int cat = bit_category(v);
+            vis.ac((run << 4) | cat, cat, (u32)(v < 0 ? v - 1 : v) & ((1u << cat) - 1u));
+            run = 0;
+        } else {
+            ++run;
+        }
+    }
+    if (run != 0) vis.eob();
+}
+
+__device__ __forceinline__ void load_block(const int16_t* coef, long long b, u32 (&w)[32]) {
+    const uint4* src = (const uint4*)(coef + b * 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint4 t = src[i];
+        w[4 * i] = t.x;
+        w[4 * i + 1] = t.y;
+        w[4 * i + 2] = t.z;
+        w[4 * i + 3] = t.w;
+    }
+}
+
+constexpr int kEntThreads = 256;
+
+// ---- histograms -------------------------------------------------------------------------
+struct HistVisitor {
+    u32* dcHist;
+    u32* acHist;
+    __device__ __forceinline__ void dc(int cat, u32) { atomicAdd(&dcHist[cat], 1u); }
+    __device__ __forceinline__ void ac(int sym, int, u32) { atomicAdd(&acHist[sym], 1u); }
+    __device__ __forceinline__ void zrl(int n) { atomicAdd(&acHist[0xF0], (u32)n); }
+    __device__ __forceinline__ void eob() { atomicAdd(&acHist[0], 1u); }
+};
+
+__global__ __launch_bounds__(kEntThreads) void k_histogram(KGeom g, const int16_t* __restrict__ coef,
+                                                           u64* __restrict__ hist) {
+    __shared__ u32 lh[4 * 256];   // DC-Y, DC-C, AC-Y, AC-C (Encoder.cpp:368-416)
+    for (int i = threadIdx.x; i < 1024; i += kEntThreads) lh[i] = 0;
+    __syncthreads();
+    for (long long b = (long long)blockIdx.x * kEntThreads + threadIdx.x; b < g.totalBlocks;
+         b += (long long)gridDim.x * kEntThreads) {
+        const long long m = b / g.bpm;
+        const int k = (int)(b - m * g.bpm);
+        const int c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
+        u32 w[32];
+        load_block(coef, b, w);
+        const int pred = dc_predictor(g, coef, b, m, k, c);
+        const int t = c == 0 ? 0 : 1;
+        HistVisitor vis{lh + 256 * t, lh + 512 + 256 * t};
+        walk_block(w, pred, vis);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += kEntThreads)
+        if (lh[i] != 0) atomicAdd(&hist[i], (u64)lh[i]);
+}
+
+hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(d_hist, 0, sizeof(u64) * 1024, s);
+    if (e != hipSuccess) return e;
+    long long grid = (g.totalBlocks + kEntThreads - 1) / kEntThreads;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_histogram, dim3((unsigned)grid), dim3(kEntThreads), 0, s, g, d_coef, d_hist);
+    return hipGetLastError();
+}
+
+// ---- bit lengths -------------------------------------------------------------------------
+struct LengthVisitor {
+    const u32* dcTab;
+    const u32* acTab;
+    u32 bits;
+    __device__ __forceinline__ void dc(int cat, u32) { bits += (dcTab[cat] >> 16) + cat; }
+    __device__ __forceinline__ void ac(int sym, int cat, u32) { bits += (acTab[sym] >> 16) + cat; }
+    __device__ __forceinline__ void zrl(int n) { bits += n * (acTab[0xF0] >> 16); }
+    __device__ __forceinline__ void eob() { bits += acTab[0] >> 16; }
+};
+
+__global__ __launch_bounds__(kEntThreads) void k_bit_lengths(KGeom g, const int16_t* __restrict__ coef,
+                                                             const u32* __restrict__ tables,
+                                                             u32* __restrict__ bitLen) {
+    __shared__ u32 tab[4 * 256];
+    for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = tables[i];
+    __syncthreads();
+    for (long long b = (long long)blockIdx.x * kEntThreads + threadIdx.x; b < g.totalBlocks;
+         b += (long long)gridDim.x * kEntThreads) {
+        const long long m = b / g.bpm;
+        const int k = (int)(b - m * g.bpm);
+        const int c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
+        u32 w[32];
+        load_block(coef, b, w);
+        const int pred = dc_predictor(g, coef, b, m, k, c);
+        const int t = c == 0 ? 0 : 1;
+        LengthVisitor vis{tab + 256 * t, tab + 512 + 256 * t, 0u};
+        walk_block(w, pred, vis);
+        bitLen[b] = vis.bits;
+    }
+}
+
+// ---- exclusive scans ---------------------------------------------------------------------
+// out[i] = sum of in[0..i), out[n] = total.  n is read from device memory when dN is set.
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+__device__ __forceinline__ u64 wave_inclusive_scan(u64 v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Exclusive scan of one value per thread over a 256-thread workgroup; returns the
+// exclusive prefix and the workgroup total.  lds: 4 values.
+__device__ __forceinline__ u64 block_exclusive_scan(u64 v, u64* lds, u64& total) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u64 inc = wave_inclusive_scan(v);
+    __syncthreads();
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    u64 base = 0;
+    u64 sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanThreads / 64; ++i) {
+        if (i < wave) base += lds[i];
+        sum += lds[i];
+    }
+    total = sum;
+    return base + inc - v;
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(kScanThreads) void k_scan_tile_sums(const TIn* __restrict__ in, long long nHost,
+                                                                 const u64* __restrict__ dN, u64* __restrict__ tileSums) {
+    __shared__ u64 lds[4];
+    const long long n = dN ? (long long)*dN : nHost;
+    const long long tiles = (n + kScanTile - 1) / kScanTile;
+    for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const long long base = t * kScanTile + (long long)threadIdx.x * kScanItems;
+        u64 s = 0;
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i)
+            if (base + i < n) s += (u64)in[base + i];
+        u64 total;
+        block_exclusive_scan(s, lds, total);
+        if (threadIdx.x == 0) tileSums[t] = total;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_tile_offsets(long long nHost, const u64* __restrict__ dN,
+                                                                    u64* __restrict__ tileSums) {
+    __shared__ u64 lds[4];
+    const long long n = dN ? (long long)*dN : nHost;
+    const long long tiles = (n + kScanTile - 1) / kScanTile;
+    u64 carry = 0;
+    for (long long t0 = 0; t0 < tiles; t0 += kScanThreads) {
+        const long long t = t0 + threadIdx.x;
+        const u64 v = t < tiles ? tileSums[t] : 0;
+        u64 total;
+        const u64 ex = block_exclusive_scan(v, lds, total);
+        if (t < tiles) tileSums[t] = carry + ex;
+        carry += total;
+        __syncthreads();
+    }
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply(const TIn* __restrict__ in, long long nHost,
+                                                             const u64* __restrict__ dN,
+                                                             const u64* __restrict__ tileSums, u64* __restrict__ out) {
+    __shared__ u64 lds[4];
+    const long long n = dN ? (long long)*dN : nHost;
+    const long long tiles = (n + kScanTile - 1) / kScanTile;
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+    for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const long long base = t * kScanTile + (long long)threadIdx.x * kScanItems;
+        u64 vals[kScanItems];
+        u64 s = 0;
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) {
+            vals[i] = base + i < n ? (u64)in[base + i] : 0;
+            s += vals[i];
+        }
+        u64 total;
+        u64 run = tileSums[t] + block_exclusive_scan(s, lds, total);
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) {
+            if (base + i < n) out[base + i] = run;
+            run += vals[i];
+            if (base + i == n - 1) out[n] = run;
+        }
+        __syncthreads();
+    }
+}
+
+template <typename TIn>
+static hipError_t exclusive_scan(const TIn* in, long long nHost, const u64* dN, long long nMax, u64* tmp, u64* out,
+                                 hipStream_t s) {
+    long long tiles = (nMax + kScanTile - 1) / kScanTile;
+    if (tiles < 1) tiles = 1;
+    const unsigned grid = (unsigned)(tiles > 1024 ? 1024 : tiles);
+    hipLaunchKernelGGL(k_scan_tile_sums<TIn>, dim3(grid), dim3(kScanThreads), 0, s, in, nHost, dN, tmp);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanThreads), 0, s, nHost, dN, tmp);
+    hipLaunchKernelGGL(k_scan_apply<TIn>, dim3(grid), dim3(kScanThreads), 0, s, in, nHost, dN, tmp, out);
+    return hipGetLastError();
+}
+
+// ---- restart intervals -------------------------------------------------------------------
+// Bytes of every interval's unstuffed bit string, padded to a whole byte.
+__global__ void k_interval_bytes(KGeom g, const u64* __restrict__ bitOff, u64* __restrict__ ivBytes) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= g.intervals) return;
+    const long long b0 = k * g.mcusPerInterval * g.bpm;
+    long long b1 = (k + 1) * g.mcusPerInterval * g.bpm;
+    if (b1 > g.totalBlocks) b1 = g.totalBlocks;
+    ivBytes[k] = (bitOff[b1] - bitOff[b0] + 7) >> 3;
+}
+
+// Clears the part of the unstuffed buffer the bit writer will OR into and publishes the
+// byte count for the later kernels.
+__global__ void k_prepare_unstuffed(const u64* __restrict__ ivOff, long long intervals, uint4* __restrict__ buf,
+                                    long long capBytes, u64* __restrict__ result) {
+    const u64 bytes = ivOff[intervals];
+    long long clear = (long long)((bytes + kStuffChunk - 1) / kStuffChunk) * kStuffChunk + 16;
+    if (clear > capBytes) clear = capBytes;
+    const long long n16 = clear / 16;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x)
+        buf[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        result[2] = bytes;
+        result[1] = 0;
+    }
+}
+
+// ---- bit writer ------------------------------------------------------------------------
+// One thread per block appends its codes MSB first at the block's bit offset.  Words that
+// may be shared with a neighbouring block are merged with atomicOr into the zeroed
+// buffer, words owned by one block are stored.  Words are byte swapped so that memory
+// holds the big-endian bit string BitBuffer::pushBits builds (BitBuffer.cpp:128-204).
+struct EmitVisitor {
+    const u32* dcTab;
+    const u32* acTab;
+    u32* words;
+    long long word;   // index of the word being filled
+    u64 acc;          // pending bits, right aligned
+    int n;            // number of pending bits (< 32 between calls)
+    bool first;
+    __device__ __forceinline__ void flush_word() {
+        const u32 w = (u32)(acc >> (n - 32));
+        const u32 be = __builtin_bswap32(w);
+        if (first) {
+            atomicOr(&words[word], be);
+            first = false;
+        } else {
+            words[word] = be;
+        }
+        ++word;
+        n -= 32;
+    }
+    __device__ __forceinline__ void put(u32 bits, int len) {
+        acc = (acc << len) | bits;
+        n += len;
+        if (n >= 32) flush_word();
+    }
+    __device__ __forceinline__ void dc(int cat, u32 amp) {
+        const u32 e = dcTab[cat];
+        put(e & 0xffffu, (int)(e >> 16));
+        put(amp, cat);
+    }
+    __device__ __forceinline__ void ac(int sym, int cat, u32 amp) {
+        const u32 e = acTab[sym];
+        put(e & 0xffffu, (int)(e >> 16));
+        put(amp, cat);
+    }
+    __device__ __forceinline__ void zrl(int cnt) {
+        const u32 e = acTab[0xF0];
+        for (int i = 0; i < cnt; ++i) put(e & 0xffffu, (int)(e >> 16));
+    }
+    __device__ __forceinline__ void eob() {
+        const u32 e = acTab[0];
+        put(e & 0xffffu, (int)(e >> 16));
+    }
+    __device__ __forceinline__ void finish() {
+        if (n > 0) {
+            const u32 w = (u32)(acc << (32 - n));
+            atomicOr(&words[word], __builtin_bswap32(w));
+        }
+    }
+};
+
+__global__ __launch_bounds__(kEntThreads) void k_emit_bits(KGeom g, const int16_t* __restrict__ coef,
+                                                           const u32* __restrict__ tables,
+                                                           const u64* __restrict__ bitOff,
+                                                           const u64* __restrict__ ivOff, u32* __restrict__ words) {
+    __shared__ u32 tab[4 * 256];
+    for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = tables[i];
+    __syncthreads();
+    const long long blocksPerInterval = g.mcusPerInterval * g.bpm;
+    for (long long b = (long long)blockIdx.x * kEntThreads + threadIdx.x; b < g.totalBlocks;
+         b += (long long)gridDim.x * kEntThreads) {
+        const long long m = b / g.bpm;
+        const int k = (int)(b - m * g.bpm);
+        const int c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
+        const long long iv = m / g.mcusPerInterval;
+        const long long ivFirstBlock = iv * blocksPerInterval;
+        const u64 pos = ivOff[iv] * 8 + (bitOff[b] - bitOff[ivFirstBlock]);
+        u32 w[32];
+        load_block(coef, b, w);
+        const int pred = dc_predictor(g, coef, b, m, k, c);
+        const int t = c == 0 ? 0 : 1;
+        EmitVisitor vis{tab + 256 * t, tab + 512 + 256 * t, words, (long long)(pos >> 5), 0, (int)(pos & 31), true};
+        walk_block(w, pred, vis);
+        // Last block of an interval: pad to the byte boundary.  Zero padding is what the
+        // reference does (BitBuffer.cpp:12-16) and needs no write.
+        if (g.padOnes) {
+            long long last = ivFirstBlock + blocksPerInterval;
+            if (last > g.totalBlocks) last = g.totalBlocks;
+            if (b == last - 1) {
+                const int rem = vis.n & 7;   // 32-bit words keep byte alignment
+                if (rem != 0) vis.put((1u << (8 - rem)) - 1u, 8 - rem);
+            }
+        }
+        vis.finish();
+    }
+}
+
+// ---- byte stuffing -----------------------------------------------------------------------
+__device__ __forceinline__ int count_ff(u32 w) {
+    // A byte is 0xFF iff all its bits are set: fold the 8 bits of every byte into bit 0.
+    u32 t = w & (w >> 4);
+    t &= t >> 2;
+    t &= t >> 1;
+    return __popc(t & 0x01010101u);
+}
+
+__global__ __launch_bounds__(256) void k_count_ff(const uint4* __restrict__ buf, const u64* __restrict__ result,
+                                                  u32* __restrict__ ffCount) {
+    __shared__ u64 lds[4];
+    const u64 bytes = result[2];
+    const long long chunks = (long long)((bytes + kStuffChunk - 1) / kStuffChunk);
+    for (long long ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+        const long long i0 = ch * kStuffChunk + (long long)threadIdx.x * 16;
+        int cnt = 0;
+        if ((u64)i0 < bytes) {
+            const uint4 v = buf[i0 / 16];
+            // Bytes past the end are zero (cleared), so they never count.
+            cnt = count_ff(v.x) + count_ff(v.y) + count_ff(v.z) + count_ff(v.w);
+        }
+        u64 total;
+        block_exclusive_scan((u64)cnt, lds, total);
+        if (threadIdx.x == 0) ffCount[ch] = (u32)total;
+        __syncthreads();
+    }
+}
+
+__global__ void k_publish_chunks(u64* __restrict__ result, u64* __restrict__ nChunks) {
+    *nChunks = (result[2] + kStuffChunk - 1) / kStuffChunk;
+}
+
+// Markers in front of the first x intervals of the band.
+__device__ __forceinline__ long long markers_before(const KGeom& g, long long x) {
+    return g.firstInterval > 0 ? x : (x > 0 ? x - 1 : 0);
+}
+
+__global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __restrict__ buf,
+                                                     const u64* __restrict__ ivOff, const u64* __restrict__ ffOff,
+                                                     u64* __restrict__ result, uint8_t* __restrict__ out,
+                                                     long long prefixLen, long long outCapacity, int writeEoi) {
+    __shared__ u64 lds[4];
+    const u64 bytes = result[2];
+    const long long chunks = (long long)((bytes + kStuffChunk - 1) / kStuffChunk);
+    for (long long ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+        const long long i0 = ch * kStuffChunk + (long long)threadIdx.x * 16;
+        uint8_t v[16];
+        int cnt = 0;
+        int valid = 0;
+        if ((u64)i0 < bytes) {
+            valid = (int)(bytes - (u64)i0 < 16 ? bytes - (u64)i0 : 16);
+            const uint4 q = *(const uint4*)(buf + i0);
+            const u32 ws[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
+            for (int j = 0; j < valid; ++j) cnt += v[j] == 0xff;
+        }
+        u64 total;
+        const u64 localFf = block_exclusive_scan((u64)cnt, lds, total);
+        if (valid > 0) {
+            // Interval that contains byte i0.
+            long long lo = 0, hi = g.intervals - 1;
+            while (lo < hi) {
+                const long long mid = (lo + hi + 1) >> 1;
+                if (ivOff[mid] <= (u64)i0) lo = mid; else hi = mid - 1;
+            }
+            long long iv = lo;
+            const bool atStart = ivOff[iv] == (u64)i0;
+            long long pos = prefixLen + i0 + (long long)(ffOff[ch] + localFf) +
+                            2 * markers_before(g, atStart ? iv : iv + 1);
+            u64 nextStart = atStart ? (u64)i0 : ivOff[iv + 1];
+            if (!atStart) ++iv;   // iv now names the next interval to start
+            bool overflow = false;
+            for (int j = 0; j < valid; ++j) {
+                if ((u64)(i0 + j) == nextStart) {
+                    const long long gi = g.firstInterval + iv;
+                    if (gi > 0) {   // RSTn in front of every interval but the image's first
+                        if (pos + 2 <= outCapacity) {
+                            out[pos] = 0xff;
+                            out[pos + 1] = (uint8_t)(0xd0 + ((gi - 1) & 7));
+                        } else {
+                            overflow = true;
+                        }
+                        pos += 2;
+                    }
+                    ++iv;
+                    nextStart = iv <= g.intervals - 1 ? ivOff[iv] : ~0ull;
+                }
+                const int extra = v[j] == 0xff ? 2 : 1;   // BitBuffer.cpp:156-161, 171-176, 190-195
+                if (pos + extra <= outCapacity) {
+                    out[pos] = v[j];
+                    if (extra == 2) out[pos + 1] = 0x00;
+                } else {
+                    overflow = true;
+                }
+                pos += extra;
+            }
+            if ((u64)(i0 + valid) == bytes) {   // this thread wrote the last scan byte
+                if (writeEoi) {
+                    if (pos + 2 <= outCapacity) {
+                        out[pos] = 0xff;
+                        out[pos + 1] = 0xd9;
+                    } else {
+                        overflow = true;
+                    }
+                    pos += 2;
+                }
+                result[0] = (u64)pos;
+            }
+            if (overflow) result[1] = 1;
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_entropy(const KGeom& g, const int16_t* d_coef, const u32* d_tables, const EntropyWorkspace& ws,
+                          uint8_t* d_out, long long prefixLen, long long outCapacity, int writeEoi, hipStream_t s) {
+    long long grid = (g.totalBlocks + kEntThreads - 1) / kEntThreads;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_bit_lengths, dim3((unsigned)grid), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.bitLen);
+    hipError_t e = exclusive_scan<u32>(ws.bitLen, g.totalBlocks, nullptr, g.totalBlocks, ws.scanTmp, ws.bitOff, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_interval_bytes, dim3((unsigned)((g.intervals + 255) / 256)), dim3(256), 0, s, g, ws.bitOff,
+                       ws.ivBytes);
+    e = exclusive_scan<u64>(ws.ivBytes, g.intervals, nullptr, g.intervals, ws.scanTmp, ws.ivOff, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_prepare_unstuffed, dim3(1024), dim3(256), 0, s, ws.ivOff, g.intervals, (uint4*)ws.unstuffed,
+                       ws.unstuffedCap, ws.result);
+    hipLaunchKernelGGL(k_emit_bits, dim3((unsigned)grid), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.bitOff,
+                       ws.ivOff, (u32*)ws.unstuffed);
+    hipLaunchKernelGGL(k_count_ff, dim3(1024), dim3(256), 0, s, (const uint4*)ws.unstuffed, ws.result, ws.ffCount);
+    hipLaunchKernelGGL(k_publish_chunks, dim3(1), dim3(1), 0, s, ws.result, ws.result + 3);
+    e = exclusive_scan<u32>(ws.ffCount, 0, ws.result + 3, ws.maxChunks, ws.scanTmp, ws.ffOff, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_stuff_bytes, dim3(1024), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.ffOff, ws.result,
+                       d_out, prefixLen, outCapacity, writeEoi);
+    return hipGetLastError();
+}
+
+}  // namespace jpeghip

@@ -1,0 +1,284 @@
+"""ctypes binding of libjpegenc_hip (the C ABI declared in include/jpegenc_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no GPU is usable the calls
+raise.  Device pointers are plain integers (e.g. ``torch.Tensor.data_ptr()``).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.abspath(os.path.join(_PKG, "..", "..", "lib", "libjpegenc_hip.so"))
+
+OK = 0
+RGB8, RGBF32 = 0, 1
+STAGE_YCBCR, STAGE_SUBSAMPLE, STAGE_ALL = 1, 2, 3
+DC, AC = 0, 1
+
+EXPORTS = [
+    "jpeg_hip_create", "jpeg_hip_destroy", "jpeg_hip_last_error", "jpeg_hip_status_string", "jpeg_hip_stream",
+    "jpeg_hip_compute_layout", "jpeg_hip_encode", "jpeg_hip_encode_host", "jpeg_hip_begin", "jpeg_hip_upload_pixels",
+    "jpeg_hip_bind_pixels", "jpeg_hip_transform", "jpeg_hip_histograms", "jpeg_hip_histograms_host",
+    "jpeg_hip_huffman_from_histogram", "jpeg_hip_write_dht", "jpeg_hip_write_headers", "jpeg_hip_set_huffman",
+    "jpeg_hip_build_huffman", "jpeg_hip_get_huffman", "jpeg_hip_emit_scan", "jpeg_hip_get_coefficients",
+    "jpeg_hip_coefficients_device", "jpeg_hip_analyze_band", "jpeg_hip_finish_band", "jpeg_hip_set_profiling",
+    "jpeg_hip_get_timings",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("sampling", C.c_int32 * 12),
+                ("qtable", (C.c_float * 64) * 3), ("restart_interval", C.c_int32), ("pad_ones", C.c_int32),
+                ("mcu_row_begin", C.c_int32), ("mcu_row_end", C.c_int32)]
+
+
+class Layout(C.Structure):
+    _fields_ = [("padded_width", C.c_int32), ("padded_height", C.c_int32), ("mcu_width", C.c_int32),
+                ("mcu_height", C.c_int32), ("mcus_per_row", C.c_int32), ("mcu_rows", C.c_int32),
+                ("band_mcu_rows", C.c_int32), ("h_factor", C.c_int32 * 3), ("v_factor", C.c_int32 * 3),
+                ("blocks_per_mcu", C.c_int32), ("blocks", C.c_int64 * 3), ("total_blocks", C.c_int64),
+                ("intervals", C.c_int64), ("max_jpeg_bytes", C.c_int64)]
+
+
+class JpegHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("jpegenc_hip status %d (%s): %s" % (status, status_string(status), message))
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libjpegenc_hip.so is not built (%s); run __graft_entry__.build()" % LIB_PATH)
+        # PyTorch ships its own libamdhip64 under the same SONAME.  A process can only run
+        # one HIP runtime, so let torch load its copy first; the encoder library then binds
+        # to that one instead of pulling in a second runtime from /opt/rocm.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+        L.jpeg_hip_create.argtypes = [i32, C.POINTER(vp)]
+        L.jpeg_hip_destroy.argtypes = [vp]
+        L.jpeg_hip_destroy.restype = None
+        L.jpeg_hip_last_error.argtypes = [vp]
+        L.jpeg_hip_last_error.restype = C.c_char_p
+        L.jpeg_hip_status_string.argtypes = [i32]
+        L.jpeg_hip_status_string.restype = C.c_char_p
+        L.jpeg_hip_stream.argtypes = [vp]
+        L.jpeg_hip_stream.restype = vp
+        L.jpeg_hip_compute_layout.argtypes = [C.POINTER(Params), C.POINTER(Layout)]
+        L.jpeg_hip_encode.argtypes = [vp, vp, i32, i64, C.POINTER(Params), vp, i64, C.POINTER(i64)]
+        L.jpeg_hip_encode_host.argtypes = [vp, vp, i32, i64, C.POINTER(Params), vp, i64, C.POINTER(i64)]
+        L.jpeg_hip_begin.argtypes = [vp, C.POINTER(Params)]
+        L.jpeg_hip_upload_pixels.argtypes = [vp, vp, i32, i64]
+        L.jpeg_hip_bind_pixels.argtypes = [vp, vp, i32, i64]
+        L.jpeg_hip_transform.argtypes = [vp, i32]
+        L.jpeg_hip_histograms.argtypes = [vp, vp]
+        L.jpeg_hip_histograms_host.argtypes = [vp, vp]
+        L.jpeg_hip_huffman_from_histogram.argtypes = [vp, vp, vp]
+        L.jpeg_hip_write_dht.argtypes = [vp, vp, i32, i32, vp, i32]
+        L.jpeg_hip_write_headers.argtypes = [C.POINTER(Params), vp, vp, vp, i32]
+        L.jpeg_hip_set_huffman.argtypes = [vp, vp, vp]
+        L.jpeg_hip_build_huffman.argtypes = [vp, vp]
+        L.jpeg_hip_get_huffman.argtypes = [vp, vp, vp]
+        L.jpeg_hip_emit_scan.argtypes = [vp, vp, i64, C.POINTER(i64)]
+        L.jpeg_hip_get_coefficients.argtypes = [vp, i32, vp, i64]
+        L.jpeg_hip_coefficients_device.argtypes = [vp]
+        L.jpeg_hip_coefficients_device.restype = vp
+        L.jpeg_hip_analyze_band.argtypes = [vp, vp, i32, i64, C.POINTER(Params), vp]
+        L.jpeg_hip_finish_band.argtypes = [vp, vp, vp, i64, C.POINTER(i64)]
+        L.jpeg_hip_set_profiling.argtypes = [vp, i32]
+        L.jpeg_hip_get_timings.argtypes = [vp, vp]
+        _lib = L
+    return _lib
+
+
+def status_string(status):
+    return lib().jpeg_hip_status_string(int(status)).decode()
+
+
+def _np(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_params(width, height, sampling, qtables, restart_interval=0, pad_ones=False, mcu_rows=None):
+    p = Params()
+    p.width, p.height = int(width), int(height)
+    s = np.asarray(sampling, np.int32).reshape(12)
+    for i in range(12):
+        p.sampling[i] = int(s[i])
+    q = np.asarray(qtables, np.float32).reshape(3, 64)
+    for c in range(3):
+        for i in range(64):
+            p.qtable[c][i] = float(q[c, i])
+    p.restart_interval = int(restart_interval)
+    p.pad_ones = 1 if pad_ones else 0
+    p.mcu_row_begin, p.mcu_row_end = (0, 0) if mcu_rows is None else (int(mcu_rows[0]), int(mcu_rows[1]))
+    return p
+
+
+def compute_layout(params):
+    lay = Layout()
+    st = lib().jpeg_hip_compute_layout(C.byref(params), C.byref(lay))
+    if st != OK:
+        raise JpegHipError(st, "invalid parameters")
+    return lay
+
+
+def huffman_from_histogram(counts):
+    """Pure host: (lengths u8[256], codes u16[256]) for a 256-bin histogram."""
+    cnt = np.ascontiguousarray(counts, np.uint64).reshape(256)
+    lengths = np.zeros(256, np.uint8)
+    codes = np.zeros(256, np.uint16)
+    st = lib().jpeg_hip_huffman_from_histogram(_np(cnt), _np(lengths), _np(codes))
+    if st != OK:
+        raise JpegHipError(st, "huffman_from_histogram")
+    return lengths, codes
+
+
+def write_dht(lengths, codes, table_id, coefficient_type):
+    lengths = np.ascontiguousarray(lengths, np.uint8).reshape(256)
+    codes = np.ascontiguousarray(codes, np.uint16).reshape(256)
+    out = np.zeros(512, np.uint8)
+    n = lib().jpeg_hip_write_dht(_np(lengths), _np(codes), int(table_id), int(coefficient_type), _np(out), out.size)
+    if n < 0:
+        raise JpegHipError(n, "write_dht")
+    return out[:n].tobytes()
+
+
+def write_headers(params, lengths, codes):
+    lengths = np.ascontiguousarray(lengths, np.uint8).reshape(4, 256)
+    codes = np.ascontiguousarray(codes, np.uint16).reshape(4, 256)
+    out = np.zeros(4096, np.uint8)
+    n = lib().jpeg_hip_write_headers(C.byref(params), _np(lengths), _np(codes), _np(out), out.size)
+    if n < 0:
+        raise JpegHipError(n, "write_headers")
+    return out[:n].tobytes()
+
+
+class Context:
+    """One encoder context on one GPU (wraps jpeg_hip_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        st = lib().jpeg_hip_create(int(device), C.byref(self._h))
+        if st != OK:
+            self._h = C.c_void_p()
+            raise JpegHipError(st, "cannot open GPU %d" % device)
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().jpeg_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != OK:
+            raise JpegHipError(st, lib().jpeg_hip_last_error(self._h).decode())
+
+    @property
+    def stream(self):
+        return lib().jpeg_hip_stream(self._h)
+
+    # ---- one shot ----
+    def encode(self, d_rgb, fmt, stride, params, d_out, capacity):
+        n = C.c_int64(0)
+        self._check(lib().jpeg_hip_encode(self._h, C.c_void_p(d_rgb), fmt, stride, C.byref(params), C.c_void_p(d_out),
+                                          capacity, C.byref(n)))
+        return n.value
+
+    def encode_host(self, rgb, params, stride=None):
+        """rgb: numpy uint8/float32 [H, W, 3] on the host -> JFIF bytes."""
+        rgb = np.ascontiguousarray(rgb)
+        fmt = RGBF32 if rgb.dtype == np.float32 else RGB8
+        if stride is None:
+            stride = rgb.strides[0]
+        lay = compute_layout(params)
+        out = np.zeros(int(lay.max_jpeg_bytes), np.uint8)
+        n = C.c_int64(0)
+        self._check(lib().jpeg_hip_encode_host(self._h, _np(rgb), fmt, stride, C.byref(params), _np(out), out.size,
+                                               C.byref(n)))
+        return out[:n.value].tobytes()
+
+    # ---- staged ----
+    def begin(self, params):
+        self._check(lib().jpeg_hip_begin(self._h, C.byref(params)))
+
+    def upload_pixels(self, rgb, stride=None):
+        rgb = np.ascontiguousarray(rgb)
+        fmt = RGBF32 if rgb.dtype == np.float32 else RGB8
+        if stride is None:
+            stride = rgb.strides[0]
+        self._check(lib().jpeg_hip_upload_pixels(self._h, _np(rgb), fmt, stride))
+
+    def bind_pixels(self, d_rgb, fmt, stride):
+        self._check(lib().jpeg_hip_bind_pixels(self._h, C.c_void_p(d_rgb), fmt, stride))
+
+    def transform(self, stages=STAGE_ALL):
+        self._check(lib().jpeg_hip_transform(self._h, stages))
+
+    def histograms_device(self, d_hist):
+        self._check(lib().jpeg_hip_histograms(self._h, C.c_void_p(d_hist)))
+
+    def histograms(self):
+        h = np.zeros((4, 256), np.uint64)
+        self._check(lib().jpeg_hip_histograms_host(self._h, _np(h)))
+        return h
+
+    def build_huffman(self, hist):
+        h = np.ascontiguousarray(hist, np.uint64).reshape(4, 256)
+        self._check(lib().jpeg_hip_build_huffman(self._h, _np(h)))
+
+    def set_huffman(self, lengths, codes):
+        lengths = np.ascontiguousarray(lengths, np.uint8).reshape(4, 256)
+        codes = np.ascontiguousarray(codes, np.uint16).reshape(4, 256)
+        self._check(lib().jpeg_hip_set_huffman(self._h, _np(lengths), _np(codes)))
+
+    def get_huffman(self):
+        lengths = np.zeros((4, 256), np.uint8)
+        codes = np.zeros((4, 256), np.uint16)
+        self._check(lib().jpeg_hip_get_huffman(self._h, _np(lengths), _np(codes)))
+        return lengths, codes
+
+    def emit_scan(self, d_out, capacity):
+        n = C.c_int64(0)
+        self._check(lib().jpeg_hip_emit_scan(self._h, C.c_void_p(d_out), capacity, C.byref(n)))
+        return n.value
+
+    def coefficients(self, channel, layout):
+        n = int(layout.blocks[channel]) * 64
+        out = np.zeros(n, np.int16)
+        self._check(lib().jpeg_hip_get_coefficients(self._h, channel, _np(out), n))
+        return out.reshape(-1, 64)
+
+    # ---- bands ----
+    def analyze_band(self, d_rgb, fmt, stride, params, d_hist):
+        self._check(lib().jpeg_hip_analyze_band(self._h, C.c_void_p(d_rgb), fmt, stride, C.byref(params),
+                                                C.c_void_p(d_hist)))
+
+    def finish_band(self, d_hist_sum, d_out, capacity):
+        n = C.c_int64(0)
+        self._check(lib().jpeg_hip_finish_band(self._h, C.c_void_p(d_hist_sum), C.c_void_p(d_out), capacity,
+                                               C.byref(n)))
+        return n.value
+
+    def set_profiling(self, enabled):
+        self._check(lib().jpeg_hip_set_profiling(self._h, 1 if enabled else 0))
+
+    def timings(self):
+        t = np.zeros(4, np.float32)
+        self._check(lib().jpeg_hip_get_timings(self._h, _np(t)))
+        return t

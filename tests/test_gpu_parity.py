@@ -1,0 +1,150 @@
+"""HIP path vs CPU oracle through the C ABI (needs an MI355X)."""
+import io
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle as O
+from jpegenc_amd import binding as B, synth, tables as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = B.Context(0)
+    yield c
+    c.close()
+
+
+SIZES = [(16, 16), (17, 17), (37, 29), (48, 32), (64, 64), (250, 130), (8, 8), (1, 1), (9, 500), (500, 9)]
+
+
+def _staged(ctx, img, scheme, qt, ri=0, pad=False):
+    prm = B.make_params(img.shape[1], img.shape[0], scheme, qt, restart_interval=ri, pad_ones=pad)
+    lay = B.compute_layout(prm)
+    ctx.begin(prm)
+    ctx.upload_pixels(img)
+    ctx.transform()
+    coef = [ctx.coefficients(c, lay) for c in range(3)]
+    hist = ctx.histograms()
+    return prm, lay, coef, hist
+
+
+@pytest.mark.parametrize("scheme", sorted(T.SCHEMES))
+@pytest.mark.parametrize("kind", ["natural", "noise"])
+def test_small_images_bit_exact(ctx, scheme, kind):
+    for (w, h) in SIZES:
+        img = synth.generate(kind, w, h, seed=w * 131 + h)
+        for tname in (["annexk", "ones"] if kind == "noise" else ["annexk", "ps12", "ps5"]):
+            qt = T.NAMED_TABLES[tname]
+            enc = O.encode(img, T.SCHEMES[scheme], qt)
+            prm, lay, coef, hist = _staged(ctx, img, T.SCHEMES[scheme], qt)
+            for c in range(3):
+                assert np.array_equal(coef[c], enc.coef[c]), (scheme, kind, w, h, tname, c)
+            assert np.array_equal(hist, enc.hist), (scheme, kind, w, h, tname)
+            got = ctx.encode_host(img, prm)
+            assert got == enc.jpeg, (scheme, kind, w, h, tname)
+
+
+@pytest.mark.parametrize("ri", [1, 2, 3, 7, 64])
+def test_restart_intervals(ctx, ri):
+    for scheme in ("444", "420", "411"):
+        for pad in (False, True):
+            img = synth.generate("noise", 123, 77, seed=ri)
+            qt = T.quality_tables(90)
+            enc = O.encode(img, T.SCHEMES[scheme], qt, restart_interval=ri, pad_ones=pad)
+            prm = B.make_params(123, 77, T.SCHEMES[scheme], qt, restart_interval=ri, pad_ones=pad)
+            assert ctx.encode_host(img, prm) == enc.jpeg, (scheme, ri, pad)
+
+
+def test_float_pixels(ctx):
+    rng = np.random.RandomState(3)
+    img = rng.rand(45, 70, 3).astype(np.float32)
+    for scheme in ("444", "420"):
+        enc = O.encode(img, T.SCHEMES[scheme], T.STANDARD_TABLES)
+        prm = B.make_params(70, 45, T.SCHEMES[scheme], T.STANDARD_TABLES)
+        assert ctx.encode_host(img, prm) == enc.jpeg
+
+
+def test_all_byte_values_and_saturated_blocks(ctx):
+    # every byte value in every channel, plus flat black / white / checkerboard extremes
+    ramp = np.arange(256, dtype=np.uint8)
+    img = np.stack([np.tile(ramp, (64, 1)), np.tile(ramp[::-1], (64, 1)), np.tile((ramp * 7 + 3).astype(np.uint8), (64, 1))], -1)
+    img[1::2] = img[1::2, ::-1]
+    chk = (((np.indices((64, 256)).sum(0)) & 1) * 255).astype(np.uint8)
+    for pic in (img, np.zeros_like(img), np.full_like(img, 255), np.stack([chk, chk, chk], -1)):
+        for scheme in ("444", "420"):
+            for tn in ("ones", "annexk"):
+                enc = O.encode(pic, T.SCHEMES[scheme], T.NAMED_TABLES[tn])
+                prm = B.make_params(256, 64, T.SCHEMES[scheme], T.NAMED_TABLES[tn])
+                assert ctx.encode_host(pic, prm) == enc.jpeg
+
+
+def test_row_stride_and_staged_emit(ctx):
+    import torch
+    img = synth.generate("natural", 100, 60)
+    padded = np.zeros((60, 100 * 3 + 20), np.uint8)
+    padded[:, :300] = img.reshape(60, 300)
+    enc = O.encode(img, T.SCHEME_420, T.STANDARD_TABLES)
+    prm = B.make_params(100, 60, T.SCHEME_420, T.STANDARD_TABLES)
+    d_rgb = torch.from_numpy(padded).cuda()
+    d_out = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    n = ctx.encode(d_rgb.data_ptr(), B.RGB8, 320, prm, d_out.data_ptr(), d_out.numel())
+    assert d_out[:n].cpu().numpy().tobytes() == enc.jpeg
+    # staged: tables from the oracle's histograms, scan only
+    ctx.begin(prm)
+    ctx.bind_pixels(d_rgb.data_ptr(), B.RGB8, 320)
+    ctx.transform()
+    ctx.build_huffman(ctx.histograms())
+    lengths, codes = ctx.get_huffman()
+    assert np.array_equal(lengths, enc.lengths) and np.array_equal(codes, enc.codes)
+    n = ctx.emit_scan(d_out.data_ptr(), d_out.numel())
+    assert d_out[:n].cpu().numpy().tobytes() == enc.scan
+
+
+def test_output_capacity_is_checked(ctx):
+    import torch
+    img = synth.generate("noise", 64, 64)
+    prm = B.make_params(64, 64, T.SCHEME_444, T.NAMED_TABLES["ones"])
+    d_rgb = torch.from_numpy(img).cuda()
+    d_out = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with pytest.raises(B.JpegHipError) as e:
+        ctx.encode(d_rgb.data_ptr(), B.RGB8, 192, prm, d_out.data_ptr(), 2000)
+    assert e.value.status == -3
+
+
+def test_1080p_420_standard_tables(ctx):
+    from PIL import Image
+    img = synth.generate("natural", 1920, 1080)
+    enc = O.encode(img, T.SCHEME_420, T.STANDARD_TABLES)
+    prm = B.make_params(1920, 1080, T.SCHEME_420, T.STANDARD_TABLES)
+    got = ctx.encode_host(img, prm)
+    assert got == enc.jpeg
+    dec = np.array(Image.open(io.BytesIO(got)).convert("RGB"))
+    ref = np.array(Image.open(io.BytesIO(enc.jpeg)).convert("RGB"))
+    assert np.array_equal(dec, ref)   # decoded PSNR is identical by construction
+
+
+def test_4k_444_q90(ctx):
+    img = synth.generate("natural", 3840, 2160)
+    qt = T.quality_tables(90)
+    enc = O.encode(img, T.SCHEME_444, qt)
+    prm, lay, coef, hist = _staged(ctx, img, T.SCHEME_444, qt)
+    mism = sum(int(np.count_nonzero(coef[c] != enc.coef[c])) for c in range(3))
+    assert mism == 0
+    assert ctx.encode_host(img, prm) == enc.jpeg
+
+
+def test_noise_q100_worst_case(ctx):
+    img = synth.generate("noise", 1024, 1024)
+    qt = T.quality_tables(100)
+    for scheme in ("444", "420"):
+        enc = O.encode(img, T.SCHEMES[scheme], qt)
+        prm = B.make_params(1024, 1024, T.SCHEMES[scheme], qt)
+        got = ctx.encode_host(img, prm)
+        assert hashlib.sha256(got).hexdigest() == hashlib.sha256(enc.jpeg).hexdigest()
+        assert enc.lengths.max() == 16
