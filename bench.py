@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X JPEG encode hot path.
+
+One step = one full encode of the workload image (RGB8 resident in HBM -> JFIF bytes
+resident in HBM): fused transform, histograms, [histogram all-reduce], Huffman tables,
+bit writer, byte stuffing.  With N > 1 ranks the image is sharded by restart intervals,
+one band of MCU rows per GPU (strong scaling), and the only collective is the 8 KiB
+histogram all-reduce.
+
+  python bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "jpeg-encoder_amd", "python"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from jpegenc_amd import binding as B, sharding, synth, synth_torch, tables as T  # noqa: E402
+
+WORKLOADS = {
+    # name: (width, height, scheme, quality, image kind, description)
+    "16k_420_q90": (16384, 16384, "420", 90, "natural",
+                    "16384x16384 synthetic natural-like RGB8, 4:2:0, q=90, restart interval = 1 MCU row, "
+                    "sharded by MCU rows over the ranks"),
+    "4k_444_q90": (3840, 2160, "444", 90, "natural", "3840x2160 synthetic natural-like RGB8, 4:4:4, q=90"),
+    "8k_noise_q100_444": (8192, 8192, "444", 100, "noise", "8192x8192 uniform noise, 4:4:4, q=100 (all-ones tables)"),
+    "8k_noise_q100_420": (8192, 8192, "420", 100, "noise", "8192x8192 uniform noise, 4:2:0, q=100 (all-ones tables)"),
+    "1080p_420_q90": (1920, 1080, "420", 90, "natural", "1920x1080 synthetic natural-like RGB8, 4:2:0, q=90"),
+}
+HBM_PEAK_GBPS = 8000.0
+
+
+def algorithmic_bytes(lay):
+    """Fused transform: RGB8 read once + int16 coefficients written once (band)."""
+    px = lay.padded_width * lay.band_mcu_rows * lay.mcu_height
+    return 3 * px + 2 * 64 * int(lay.total_blocks)
+
+
+def cpu_baseline(width, height, scheme, qt, kind):
+    """The CPU oracle (a port of the reference path) timed on a bounded crop of the workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    w, h = min(width, 8192), min(height, 4096)
+    img = synth.generate(kind, w, h)
+    ri = T.padded_size(w, h, scheme)[0] // T.step_size(scheme)[0] if height > 4096 else 0
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    best = None
+    t_end = time.time() + 20.0
+    runs = 0
+    while runs < 2 or (time.time() < t_end and runs < 8):
+        t0 = time.perf_counter()
+        oracle.encode(img, scheme, qt, restart_interval=ri)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        runs += 1
+    return {"value": round(w * h / 1e6 / best, 2), "unit": "MP/s", "cores": threads, "kind": "port",
+            "sample": "%dx%d crop of the workload image, same scheme and tables, best of %d runs, OpenMP threads=%d"
+                      % (w, h, runs, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="16k_420_q90", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    width, height, sname, quality, kind, desc = WORKLOADS[args.workload]
+    scheme, qt = T.SCHEMES[sname], T.quality_tables(quality)
+    ctx = B.Context(local_rank)
+    ctx.set_profiling(True)
+
+    sharded = world > 1 or args.workload == "16k_420_q90"
+    if sharded:
+        enc = sharding.HipBandEncoder(ctx, B, width, height, scheme, qt, world, rank)
+        params, lay = enc.params, enc.layout
+        y0, y1 = enc.pixel_rows
+    else:
+        params = B.make_params(width, height, scheme, qt)
+        lay = B.compute_layout(params)
+        y0, y1 = 0, height
+    rgb = synth_torch.generate(kind, width, height, device=dev, y0=y0, y1=y1)
+    stride = width * 3
+    hist = torch.zeros((4, 256), dtype=torch.int64, device=dev)
+    # Output capacity: the worst case bound is huge; 1.5 bytes per pixel of the band plus
+    # slack covers every workload here (noise at q=100 needs about 1.1 B/px in 4:2:0 and
+    # 2.9 B/px in 4:4:4, which gets its own bound).
+    per_px = 3.2 if kind == "noise" else 1.0
+    cap = int((y1 - y0 + lay.mcu_height) * lay.padded_width * per_px) + (1 << 20)
+    out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.analyze_band(rgb.data_ptr(), B.RGB8, stride, params, hist.data_ptr())
+        if world > 1:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(ext)
+            dist.all_reduce(hist)
+            ext.wait_stream(cur)
+        return ctx.finish_band(hist.data_ptr(), out.data_ptr(), cap)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        n_out = step()
+    sync()
+    kern_ms = np.zeros(4)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_out = step()
+        kern_ms += ctx.timings()
+    sync()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    kern_ms /= max(args.steps, 1)
+
+    if rank == 0:
+        mp = width * height / 1e6
+        ms_per_step = elapsed / args.steps * 1e3
+        alg = algorithmic_bytes(lay)
+        achieved = alg / (kern_ms[0] * 1e-3) / 1e9 if kern_ms[0] > 0 else 0.0
+        res = {
+            "metric": "megapixels/sec encoded (4:2:0, q=90) at 1/2/4/8 MI355X; achieved HBM GB/s",
+            "value": round(mp / (elapsed / args.steps), 1),
+            "unit": "MP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": desc, "name": args.workload, "width": width, "height": height,
+                       "sampling": sname, "quality": quality,
+                       "restart_interval_mcus": int(params.restart_interval),
+                       "parallelism": "band-per-gpu x%d" % world, "jpeg_bytes_rank0": int(n_out)},
+            "roofline": {"bound": "hbm", "kernel": "fused transform (colour, subsample, DCT, quantize, zig-zag)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg), "kernel_ms": round(float(kern_ms[0]), 4)},
+            "stage_ms": {"transform": round(float(kern_ms[0]), 4), "histogram": round(float(kern_ms[1]), 4),
+                         "entropy": round(float(kern_ms[2]), 4), "host_tables": round(float(kern_ms[3]), 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(width, height, scheme, qt, kind)
+        elif not args.no_cpu_baseline:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -389,7 +389,8 @@ template <> float normalise<float>(float s) { return s; }        // Image::setRa
 
 template <typename Sample>
 void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Scheme& sc, const float qt[3][64],
-                 int restartInterval, bool padOnes, EncodeResult& res) {
+                 int restartInterval, bool padOnes, const uint64_t* histOverride, int rstBase, int headerH,
+                 EncodeResult& res) {
     // Image::Image, Image.cpp:6-16: padded ("simulated") size.
     const int simW = W + (W % sc.stepW == 0 ? 0 : sc.stepW - W % sc.stepW);
     const int simH = H + (H % sc.stepH == 0 ? 0 : sc.stepH - H % sc.stepH);
@@ -537,7 +538,8 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
             for (u8 s : bs.acSym) res.hist[2 + t][s]++;
         }
     }
-    for (int t = 0; t < 4; ++t) buildHuffman(res.hist[t], res.tables[t]);
+    // Extension (sharded images): tables may come from histograms summed over all bands.
+    for (int t = 0; t < 4; ++t) buildHuffman(histOverride ? histOverride + 256 * t : res.hist[t], res.tables[t]);
 
     // Encoder::serialize, Encoder.cpp:439-488.
     BitSink sink;
@@ -546,7 +548,8 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
                           0x00, 0x00, 0x48, 0x00, 0x48, 0x00, 0x00};          // JPEGSegments.h:50-75
     hdr.insert(hdr.end(), soiApp0, soiApp0 + sizeof soiApp0);
     {                                                                           // JPEGSegments.h:77-100
-        const u8 sof[] = {0xff, 0xc0, 0x00, 0x11, 0x08, (u8)(H >> 8), (u8)H, (u8)(W >> 8), (u8)W, 0x03};
+        const int fh = headerH > 0 ? headerH : H;   // extension: a band reports the whole image's height
+        const u8 sof[] = {0xff, 0xc0, 0x00, 0x11, 0x08, (u8)(fh >> 8), (u8)fh, (u8)(W >> 8), (u8)W, 0x03};
         hdr.insert(hdr.end(), sof, sof + sizeof sof);
         for (int c = 0; c < 3; ++c) {
             hdr.push_back((u8)(c + 1));
@@ -598,7 +601,7 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
     for (size_t m = 0; m < nMcu; ++m) {
         if (restartInterval > 0 && m > 0 && m % restartInterval == 0) {   // extension: RSTn
             sink.fillToByte(padOnes);
-            const u8 rst[2] = {0xff, (u8)(0xd0 + ((m / restartInterval - 1) & 7))};
+            const u8 rst[2] = {0xff, (u8)(0xd0 + ((rstBase + m / restartInterval - 1) & 7))};
             sink.pushBytes(rst, 2);
         }
         for (int c = 0; c < 3; ++c) {
@@ -684,16 +687,21 @@ struct OrcResult {
 // scheme: 12 ints, per channel {widthFactor, widthMethod, heightFactor, heightMethod},
 // method 0 = Subsampling, 1 = Average.  qt: 3 x 64 floats, natural order.
 // sampleType 0: rgb is uint8 (value/255.0f is applied), 1: rgb is float in [0,1].
+// histOverride (may be null), rstBase and headerH serve band-wise encodes of a sharded
+// image: tables from summed histograms, global RSTn numbering, whole-image height in SOF0.
 void* orc_encode(const void* rgb, int sampleType, int W, int H, int64_t strideSamples, const int32_t* scheme,
-                 const float* qt, int restartInterval, int padOnes) {
+                 const float* qt, int restartInterval, int padOnes, const uint64_t* histOverride, int rstBase,
+                 int headerH) {
     OrcResult* o = new OrcResult();
     Scheme sc(scheme);
     float q[3][64];
     memcpy(q, qt, sizeof q);
     if (sampleType == 0)
-        encodeImage<u8>((const u8*)rgb, W, H, (size_t)strideSamples, sc, q, restartInterval, padOnes != 0, o->r);
+        encodeImage<u8>((const u8*)rgb, W, H, (size_t)strideSamples, sc, q, restartInterval, padOnes != 0,
+                        histOverride, rstBase, headerH, o->r);
     else
-        encodeImage<float>((const float*)rgb, W, H, (size_t)strideSamples, sc, q, restartInterval, padOnes != 0, o->r);
+        encodeImage<float>((const float*)rgb, W, H, (size_t)strideSamples, sc, q, restartInterval, padOnes != 0,
+                           histOverride, rstBase, headerH, o->r);
     return o;
 }
 void orc_free(void* h) { delete (OrcResult*)h; }

@@ -30,7 +30,7 @@ def lib():
         L = C.CDLL(_SO)
         L.orc_encode.restype = C.c_void_p
         L.orc_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
-                                 C.c_int]
+                                 C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_free.argtypes = [C.c_void_p]
         for name in ("orc_jpeg_size", "orc_scan_offset", "orc_scan_len"):
             getattr(L, name).restype = C.c_int64
@@ -134,8 +134,12 @@ class Encoded:
         return self.jpeg[self.scan_offset:self.scan_offset + self.scan_len]
 
 
-def encode(rgb, scheme, qtables, restart_interval=0, pad_ones=False, stride=None):
-    """rgb: uint8 or float32 array [H, W, 3]; scheme: 12 ints; qtables: float32 [3, 64]."""
+def encode(rgb, scheme, qtables, restart_interval=0, pad_ones=False, stride=None, hist_override=None, rst_base=0,
+           header_height=0):
+    """rgb: uint8 or float32 array [H, W, 3]; scheme: 12 ints; qtables: float32 [3, 64].
+
+    hist_override / rst_base / header_height: band of a sharded image (tables from summed
+    histograms, global RSTn numbering, whole-image height in the frame header)."""
     L = lib()
     rgb = np.asarray(rgb)
     h, w = rgb.shape[0], rgb.shape[1]
@@ -150,7 +154,11 @@ def encode(rgb, scheme, qtables, restart_interval=0, pad_ones=False, stride=None
         stride = w * 3
     sch = np.ascontiguousarray(scheme, np.int32).reshape(12)
     qt = np.ascontiguousarray(qtables, np.float32).reshape(3, 64)
-    hnd = L.orc_encode(_p(rgb), st, w, h, stride, _p(sch), _p(qt), int(restart_interval), int(pad_ones))
+    ho = None
+    if hist_override is not None:
+        ho = np.ascontiguousarray(hist_override, np.uint64).reshape(4, 256)
+    hnd = L.orc_encode(_p(rgb), st, w, h, stride, _p(sch), _p(qt), int(restart_interval), int(pad_ones),
+                       _p(ho) if ho is not None else None, int(rst_base), int(header_height))
     try:
         n = L.orc_jpeg_size(hnd)
         jpeg = np.zeros(n, np.uint8)
