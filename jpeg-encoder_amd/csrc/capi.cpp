@@ -108,6 +108,7 @@ struct DevBuf {
 };
 
 struct Pinned {
+    float qtab[3 * 192];   // divisors, then the high and low parts of their reciprocals
     uint64_t hist[4 * 256];
     uint32_t tables[4 * 256];
     uint64_t result[4];
@@ -206,7 +207,7 @@ int ensure_workspace(jpeg_hip_ctx* ctx) {
     int64_t scanItems = nb > maxChunks ? nb : maxChunks;
     if (g.intervals > scanItems) scanItems = g.intervals;
     HIP_TRY(ctx, ctx->coef.ensure((size_t)nb * 128));
-    HIP_TRY(ctx, ctx->qtab.ensure(3 * 64 * sizeof(float)));
+    HIP_TRY(ctx, ctx->qtab.ensure(sizeof ctx->pin->qtab));
     HIP_TRY(ctx, ctx->hist.ensure(1024 * sizeof(uint64_t)));
     HIP_TRY(ctx, ctx->tables.ensure(1024 * sizeof(uint32_t)));
     HIP_TRY(ctx, ctx->bitLen.ensure((size_t)nb * 4));
@@ -417,9 +418,17 @@ int jpeg_hip_begin(jpeg_hip_ctx* ctx, const jpeg_hip_params* params) {
     ctx->hasPixels = ctx->transformed = ctx->hasTables = false;
     const int ws = ensure_workspace(ctx);
     if (ws != JPEG_HIP_OK) return ws;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->qtab.p, params->qtable, 3 * 64 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    // The parameter block is caller memory: finish the copy before returning.
+    // Earlier work on the stream may still read the pinned staging block.
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 192; ++i) {
+        const float q = params->qtable[i / 64][i % 64];
+        const double inv = 1.0 / (double)q;
+        const float hi = (float)inv;
+        ctx->pin->qtab[i] = q;
+        ctx->pin->qtab[192 + i] = hi;
+        ctx->pin->qtab[384 + i] = (float)(inv - (double)hi);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->qtab.p, ctx->pin->qtab, sizeof ctx->pin->qtab, hipMemcpyHostToDevice, ctx->stream));
     return JPEG_HIP_OK;
 }
 

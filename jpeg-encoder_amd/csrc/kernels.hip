@@ -5,6 +5,8 @@
 // the compiler's correctly rounded fp32 division, rounding is v_rndne_f32 (ties to even).
 #include "kernels.h"
 
+#include <cstdlib>
+
 #include "jpegenc_hip.h"
 
 namespace jpeghip {
@@ -174,9 +176,268 @@ __global__ __launch_bounds__(kGenThreads) void k_transform_generic(KGeom g, cons
     for (int i = 0; i < 8; ++i) dst[i] = make_uint4(packed[4 * i], packed[4 * i + 1], packed[4 * i + 2], packed[4 * i + 3]);
 }
 
+// ----------------------------------------------------------------------------------------
+// Fast fused transforms for byte pixels (4:2:0 and 4:4:4).
+//
+// Both divisions of the path are replaced by sequences that are proven to give the same
+// correctly rounded quotient:
+//   byte / 255.0f   == fma(x, hi, x * lo) with hi + lo = 1/255 to 48 bits (all 256 bytes)
+//   value / q[i]    == fma(x, rhi, x * rlo) with rhi + rlo = 1/q to 48 bits, for every
+//                      integer divisor 1..255 and every float x: the quotient can never
+//                      sit closer than 2^-33 (relative) to a rounding boundary, the
+//                      two-term product is accurate to 2^-47.
+// (oracle/tools/verify_exact_division.c checks both exhaustively).  Rounding to the
+// nearest-even integer is done by adding 1.5 * 2^23, which leaves the integer in the low
+// mantissa bits.
+// ----------------------------------------------------------------------------------------
+#define INV255_HI 0x1.010102p-8f
+#define INV255_LO -0x1.fdfdfep-33f
+#define ROUND_MAGIC 12582912.0f
+
+__device__ __forceinline__ float unorm8(u32 w, int k) {
+    const float x = (float)((w >> (8 * k)) & 0xffu);
+    return __builtin_fmaf(x, INV255_HI, x * INV255_LO);
+}
+
+// The three channels of pixel i of an 8-pixel row held in six dwords.
+__device__ __forceinline__ void pixel_ycbcr(const u32 (&raw)[6], int i, float& y, float& cb, float& cr) {
+    const float r = unorm8(raw[(3 * i) >> 2], (3 * i) & 3);
+    const float g = unorm8(raw[(3 * i + 1) >> 2], (3 * i + 1) & 3);
+    const float b = unorm8(raw[(3 * i + 2) >> 2], (3 * i + 2) & 3);
+    float t = 0.2990f * r;
+    t = t + 0.5870f * g;
+    y = t + 0.1140f * b;
+    t = -0.1687f * r;
+    t = t + -0.3312f * g;
+    t = t + 0.5000f * b;
+    cb = t + 0.5f;
+    t = 0.5000f * r;
+    t = t + -0.4186f * g;
+    t = t + -0.0813f * b;
+    cr = t + 0.5f;
+}
+
+// Row of 8 pixels starting at (x0, y): one aligned 24-byte read inside the image,
+// byte-wise edge replication (Image.cpp:63-139) outside.
+__device__ __forceinline__ void load_row8(const unsigned char* __restrict__ rgb, long long stride, int x0, int y,
+                                          bool interior, int W, int rows, u32 (&raw)[6]) {
+    if (interior) {
+        const uint3* p = (const uint3*)(rgb + (long long)y * stride + (long long)x0 * 3);
+        const uint3 a = p[0], b = p[1];
+        raw[0] = a.x; raw[1] = a.y; raw[2] = a.z; raw[3] = b.x; raw[4] = b.y; raw[5] = b.z;
+    } else {
+        const unsigned char* row = rgb + (long long)min(y, rows - 1) * stride;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) raw[d] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned char* px = row + (long long)min(x0 + i, W - 1) * 3;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const int bidx = 3 * i + ch;
+                raw[bidx >> 2] |= (u32)px[ch] << ((bidx & 3) * 8);
+            }
+        }
+    }
+}
+
+// x255, transform, quantize with the reciprocal pairs of channel table `tab`, zig-zag,
+// and store the block's 128 bytes.
+__device__ __forceinline__ void finish_block(float (&v)[64], const float* __restrict__ rhi,
+                                             const float* __restrict__ rlo, int16_t* __restrict__ dstBlock) {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = v[i] * 255.0f;   // SIMD256.h:484-494
+    aan2d(v);
+    u32 packed[32];
+#pragma unroll
+    for (int z = 0; z < 64; z += 2) {
+        const int a = kZZ[z], b = kZZ[z + 1];
+        const float qa = __builtin_fmaf(v[a], rhi[a], v[a] * rlo[a]) + ROUND_MAGIC;
+        const float qb = __builtin_fmaf(v[b], rhi[b], v[b] * rlo[b]) + ROUND_MAGIC;
+        packed[z >> 1] = __builtin_amdgcn_perm(__float_as_uint(qb), __float_as_uint(qa), 0x05040100u);
+    }
+    uint4* dst = (uint4*)dstBlock;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = make_uint4(packed[4 * i], packed[4 * i + 1], packed[4 * i + 2], packed[4 * i + 3]);
+}
+
+// 4:2:0 (SamplingScheme.h:63-66): four threads per 16x16 MCU, one per luma block.  Each
+// thread converts its 64 pixels once, keeps Y in registers and reduces Cb/Cr 2x2 on the
+// fly -- horizontal pairs first, then the two rows, as the in-place passes of
+// Encoder.cpp:58-64 and 118-126 do -- into a 4x4 corner of the MCU's chroma blocks in
+// LDS.  After the barrier the first two waves transform the 128 chroma blocks.
+constexpr int k420Mcus = 64;
+constexpr int kChromaPitch = 68;   // floats per block in LDS: keeps 16-byte rows, spreads banks
+
+template <int kMinWaves>
+__global__ __launch_bounds__(256, kMinWaves) void k_transform_420(KGeom g, const unsigned char* __restrict__ rgb,
+                                                                  const float* __restrict__ qtab,
+                                                                  int16_t* __restrict__ coef) {
+    __shared__ __attribute__((aligned(16))) float chroma[2 * k420Mcus * kChromaPitch];
+    const float* rhi = qtab + 192;
+    const float* rlo = qtab + 384;
+    const int tid = threadIdx.x, q = tid & 3, ml = tid >> 2;
+    const long long m = (long long)blockIdx.x * k420Mcus + ml;
+    if (m < g.nMcu) {
+        const int my = (int)(m / g.mcusPerRow), mx = (int)(m - (long long)my * g.mcusPerRow);
+        const int x0 = mx * 16 + (q & 1) * 8, y0 = my * 16 + (q >> 1) * 8;
+        const bool interior = x0 + 8 <= g.W && y0 + 8 <= g.rowsAvail;
+        float v[64];
+        float* cbDst = chroma + ml * kChromaPitch + (q >> 1) * 32 + (q & 1) * 4;
+        float* crDst = cbDst + k420Mcus * kChromaPitch;
+#pragma unroll
+        for (int rp = 0; rp < 4; ++rp) {
+            float hcb[2][4], hcr[2][4];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = 2 * rp + rr;
+                u32 raw[6];
+                load_row8(rgb, g.strideBytes, x0, y0 + r, interior, g.W, g.rowsAvail, raw);
+                float cb[8], cr[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pixel_ycbcr(raw, i, v[8 * r + i], cb[i], cr[i]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {   // (a + b) / 2.0f, SIMD256.h:260-277
+                    hcb[rr][j] = (cb[2 * j] + cb[2 * j + 1]) * 0.5f;
+                    hcr[rr][j] = (cr[2 * j] + cr[2 * j + 1]) * 0.5f;
+                }
+            }
+            float4 ocb, ocr;   // (row0 + row1) / 2.0f, SIMD256.h:295-304
+            ocb.x = (hcb[0][0] + hcb[1][0]) * 0.5f; ocb.y = (hcb[0][1] + hcb[1][1]) * 0.5f;
+            ocb.z = (hcb[0][2] + hcb[1][2]) * 0.5f; ocb.w = (hcb[0][3] + hcb[1][3]) * 0.5f;
+            ocr.x = (hcr[0][0] + hcr[1][0]) * 0.5f; ocr.y = (hcr[0][1] + hcr[1][1]) * 0.5f;
+            ocr.z = (hcr[0][2] + hcr[1][2]) * 0.5f; ocr.w = (hcr[0][3] + hcr[1][3]) * 0.5f;
+            *(float4*)(cbDst + rp * 8) = ocb;
+            *(float4*)(crDst + rp * 8) = ocr;
+        }
+        finish_block(v, rhi, rlo, coef + (m * 6 + q) * 64);
+    }
+    __syncthreads();
+    if (tid < 2 * k420Mcus) {
+        const int ch = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave 0: Cb, wave 1: Cr
+        const int ml2 = tid & 63;
+        const long long m2 = (long long)blockIdx.x * k420Mcus + ml2;
+        if (m2 < g.nMcu) {
+            const float4* src = (const float4*)(chroma + (ch * k420Mcus + ml2) * kChromaPitch);
+            float v[64];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float4 t = src[i];
+                v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+            }
+            finish_block(v, rhi + 64 * (1 + ch), rlo + 64 * (1 + ch), coef + (m2 * 6 + 4 + ch) * 64);
+        }
+    }
+}
+
+// 4:4:4 (SamplingScheme.h:48-51): one thread per 8x8 pixel block.  The 192 raw bytes stay
+// in registers; each channel is converted, transformed and stored in turn.
+constexpr int k444Threads = 64;
+
+template <int C>
+__device__ __forceinline__ void channel_444(const u32 (&raw)[8][6], const float* __restrict__ rhi,
+                                            const float* __restrict__ rlo, int16_t* __restrict__ dst) {
+    float v[64];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float rr = unorm8(raw[r][(3 * i) >> 2], (3 * i) & 3);
+            const float gg = unorm8(raw[r][(3 * i + 1) >> 2], (3 * i + 1) & 3);
+            const float bb = unorm8(raw[r][(3 * i + 2) >> 2], (3 * i + 2) & 3);
+            float t;
+            if (C == 0) {
+                t = 0.2990f * rr;
+                t = t + 0.5870f * gg;
+                t = t + 0.1140f * bb;
+            } else if (C == 1) {
+                t = -0.1687f * rr;
+                t = t + -0.3312f * gg;
+                t = t + 0.5000f * bb;
+                t = t + 0.5f;
+            } else {
+                t = 0.5000f * rr;
+                t = t + -0.4186f * gg;
+                t = t + -0.0813f * bb;
+                t = t + 0.5f;
+            }
+            v[8 * r + i] = t;
+        }
+    }
+    finish_block(v, rhi + 64 * C, rlo + 64 * C, dst);
+}
+
+template <int kMinWaves, bool kRecompute>
+__global__ __launch_bounds__(k444Threads, kMinWaves) void k_transform_444(KGeom g,
+                                                                          const unsigned char* __restrict__ rgb,
+                                                                          const float* __restrict__ qtab,
+                                                                          int16_t* __restrict__ coef) {
+    const float* rhi = qtab + 192;
+    const float* rlo = qtab + 384;
+    const long long m = (long long)blockIdx.x * k444Threads + threadIdx.x;
+    if (m >= g.nMcu) return;
+    const int my = (int)(m / g.mcusPerRow), mx = (int)(m - (long long)my * g.mcusPerRow);
+    const int x0 = mx * 8, y0 = my * 8;
+    const bool interior = x0 + 8 <= g.W && y0 + 8 <= g.rowsAvail;
+    u32 raw[8][6];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) load_row8(rgb, g.strideBytes, x0, y0 + r, interior, g.W, g.rowsAvail, raw[r]);
+    int16_t* dst = coef + m * 3 * 64;
+    channel_444<0>(raw, rhi, rlo, dst);
+    if (kRecompute) {   // keep the byte->float conversions from being shared across channels
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int d = 0; d < 6; ++d) asm volatile("" : "+v"(raw[r][d]));
+    }
+    channel_444<1>(raw, rhi, rlo, dst + 64);
+    if (kRecompute) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int d = 0; d < 6; ++d) asm volatile("" : "+v"(raw[r][d]));
+    }
+    channel_444<2>(raw, rhi, rlo, dst + 128);
+}
+
+static bool scheme_is(const KGeom& g, int wf, int hf, int method) {
+    if (g.wf[0] != 1 || g.hf[0] != 1) return false;
+    for (int c = 1; c < 3; ++c) {
+        if (g.wf[c] != wf || g.hf[c] != hf) return false;
+        if (wf > 1 && g.wm[c] != method) return false;
+        if (hf > 1 && g.hm[c] != method) return false;
+    }
+    return true;
+}
+
 hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef, hipStream_t s) {
-    const long long grid = (g.totalBlocks + kGenThreads - 1) / kGenThreads;
-    hipLaunchKernelGGL(k_transform_generic, dim3((unsigned)grid), dim3(kGenThreads), 0, s, g, d_rgb, d_qtab, d_coef);
+    const bool bytesAligned = g.sampleFormat == JPEG_HIP_RGB8 && g.stages == JPEG_HIP_STAGE_ALL &&
+                              (g.strideBytes & 3) == 0 && ((uintptr_t)d_rgb & 3) == 0;
+    if (bytesAligned && scheme_is(g, 2, 2, JPEG_HIP_AVERAGE)) {
+        const long long grid = (g.nMcu + k420Mcus - 1) / k420Mcus;
+        const char* v = getenv("JPEGHIP_VARIANT");
+        if (v && v[0] == '3')
+            hipLaunchKernelGGL(k_transform_420<3>, dim3((unsigned)grid), dim3(256), 0, s, g, (const unsigned char*)d_rgb,
+                               d_qtab, d_coef);
+        else
+            hipLaunchKernelGGL(k_transform_420<2>, dim3((unsigned)grid), dim3(256), 0, s, g, (const unsigned char*)d_rgb,
+                               d_qtab, d_coef);
+    } else if (bytesAligned && scheme_is(g, 1, 1, JPEG_HIP_SUBSAMPLING)) {
+        const long long grid = (g.nMcu + k444Threads - 1) / k444Threads;
+        const char* v = getenv("JPEGHIP_VARIANT");
+        if (v && v[0] == '3')
+            hipLaunchKernelGGL((k_transform_444<3, true>), dim3((unsigned)grid), dim3(k444Threads), 0, s, g,
+                               (const unsigned char*)d_rgb, d_qtab, d_coef);
+        else if (v && v[0] == '4')
+            hipLaunchKernelGGL((k_transform_444<4, true>), dim3((unsigned)grid), dim3(k444Threads), 0, s, g,
+                               (const unsigned char*)d_rgb, d_qtab, d_coef);
+        else
+            hipLaunchKernelGGL((k_transform_444<2, false>), dim3((unsigned)grid), dim3(k444Threads), 0, s, g,
+                               (const unsigned char*)d_rgb, d_qtab, d_coef);
+    } else {
+        const long long grid = (g.totalBlocks + kGenThreads - 1) / kGenThreads;
+        hipLaunchKernelGGL(k_transform_generic, dim3((unsigned)grid), dim3(kGenThreads), 0, s, g, d_rgb, d_qtab, d_coef);
+    }
     return hipGetLastError();
 }
 
