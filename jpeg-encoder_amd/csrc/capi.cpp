@@ -197,12 +197,14 @@ void fill_kgeom(jpeg_hip_ctx* ctx) {
     k.intervals = g.intervals;
     k.firstInterval = g.firstInterval;
     k.padOnes = ctx->prm.pad_ones ? 1 : 0;
+    k.writeEoi = 0;
 }
 
 int ensure_workspace(jpeg_hip_ctx* ctx) {
     const Geometry& g = ctx->geo;
     const int64_t nb = g.totalBlocks;
-    const int64_t unstuffedCap = (worst_case_scan_bytes(nb) + kStuffChunk + 63) / 16 * 16;
+    // Entropy-coded bits plus the RSTn/EOI markers the bit writer places in the stream.
+    const int64_t unstuffedCap = (worst_case_scan_bytes(nb) + 2 * g.intervals + 2 + kStuffChunk + 63) / 16 * 16;
     const int64_t maxChunks = (unstuffedCap + kStuffChunk - 1) / kStuffChunk;
     int64_t scanItems = nb > maxChunks ? nb : maxChunks;
     if (g.intervals > scanItems) scanItems = g.intervals;
@@ -265,6 +267,7 @@ int build_tables(jpeg_hip_ctx* ctx, const uint64_t* hist) {
 // the start of d_out (headers).
 int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capacity, int writeEoi, int64_t* outLen) {
     mark(ctx, 3);
+    ctx->kg.writeEoi = writeEoi;
     HIP_TRY(ctx, launch_entropy(ctx->kg, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, d_out,
                                 prefix, capacity, writeEoi, ctx->stream));
     mark(ctx, 4);

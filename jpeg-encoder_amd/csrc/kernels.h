@@ -26,6 +26,7 @@ struct KGeom {
     long long intervals;
     long long firstInterval;     // global index of the band's first interval
     int padOnes;
+    int writeEoi;                // the band ends the image: EOI follows its last interval
 };
 
 // Device workspace of the entropy stage (all sizes fixed by the geometry).

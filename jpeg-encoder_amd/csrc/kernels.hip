@@ -690,14 +690,23 @@ static hipError_t exclusive_scan(const TIn* in, long long nHost, const u64* dN, 
 }
 
 // ---- restart intervals -------------------------------------------------------------------
-// Bytes of every interval's unstuffed bit string, padded to a whole byte.
+// The unstuffed stream holds, per interval, an RSTn marker (every interval but the image's
+// first) and the interval's bit string padded to a whole byte; the band that ends the
+// image appends EOI.  Markers travel inside the stream so that the stuffing pass needs no
+// interval bookkeeping; it recognises them by position (is_marker_ff).
+__device__ __forceinline__ int interval_marker_bytes(const KGeom& g, long long k) {
+    return g.firstInterval + k > 0 ? 2 : 0;
+}
+
 __global__ void k_interval_bytes(KGeom g, const u64* __restrict__ bitOff, u64* __restrict__ ivBytes) {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= g.intervals) return;
     const long long b0 = k * g.mcusPerInterval * g.bpm;
     long long b1 = (k + 1) * g.mcusPerInterval * g.bpm;
     if (b1 > g.totalBlocks) b1 = g.totalBlocks;
-    ivBytes[k] = (bitOff[b1] - bitOff[b0] + 7) >> 3;
+    u64 n = ((bitOff[b1] - bitOff[b0] + 7) >> 3) + interval_marker_bytes(g, k);
+    if (k == g.intervals - 1 && g.writeEoi) n += 2;
+    ivBytes[k] = n;
 }
 
 // Clears the part of the unstuffed buffer the bit writer will OR into and publishes the
@@ -717,14 +726,19 @@ __global__ void k_prepare_unstuffed(const u64* __restrict__ ivOff, long long int
 }
 
 // ---- bit writer ------------------------------------------------------------------------
-// One thread per block appends its codes MSB first at the block's bit offset.  Words that
-// may be shared with a neighbouring block are merged with atomicOr into the zeroed
-// buffer, words owned by one block are stored.  Words are byte swapped so that memory
-// holds the big-endian bit string BitBuffer::pushBits builds (BitBuffer.cpp:128-204).
+// One thread per block appends its codes MSB first.  A workgroup's 256 blocks cover one
+// contiguous bit range; it is assembled in LDS (ds_or for the words two blocks share) and
+// copied out with coalesced stores, only the range's first and last word being merged
+// into the zeroed buffer with atomicOr.  Ranges too long for the LDS stage are written
+// straight to memory by the same code.  Words are byte swapped so that memory holds the
+// big-endian bit string BitBuffer::pushBits builds (BitBuffer.cpp:128-204).
+constexpr int kEmitStageWords = 4096;
+
 struct EmitVisitor {
     const u32* dcTab;
     const u32* acTab;
-    u32* words;
+    u32* words;       // LDS stage or the global buffer, indexed by (word - bias)
+    long long bias;
     long long word;   // index of the word being filled
     u64 acc;          // pending bits, right aligned
     int n;            // number of pending bits (< 32 between calls)
@@ -733,10 +747,10 @@ struct EmitVisitor {
         const u32 w = (u32)(acc >> (n - 32));
         const u32 be = __builtin_bswap32(w);
         if (first) {
-            atomicOr(&words[word], be);
+            atomicOr(&words[word - bias], be);
             first = false;
         } else {
-            words[word] = be;
+            words[word - bias] = be;
         }
         ++word;
         n -= 32;
@@ -767,7 +781,7 @@ struct EmitVisitor {
     __device__ __forceinline__ void finish() {
         if (n > 0) {
             const u32 w = (u32)(acc << (32 - n));
-            atomicOr(&words[word], __builtin_bswap32(w));
+            atomicOr(&words[word - bias], __builtin_bswap32(w));
         }
     }
 };
@@ -777,34 +791,78 @@ __global__ __launch_bounds__(kEntThreads) void k_emit_bits(KGeom g, const int16_
                                                            const u64* __restrict__ bitOff,
                                                            const u64* __restrict__ ivOff, u32* __restrict__ words) {
     __shared__ u32 tab[4 * 256];
-    for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = tables[i];
-    __syncthreads();
+    __shared__ u32 stage[kEmitStageWords];
+    __shared__ u64 span[2];
     const long long blocksPerInterval = g.mcusPerInterval * g.bpm;
-    for (long long b = (long long)blockIdx.x * kEntThreads + threadIdx.x; b < g.totalBlocks;
-         b += (long long)gridDim.x * kEntThreads) {
-        const long long m = b / g.bpm;
-        const int k = (int)(b - m * g.bpm);
-        const int c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
+    const long long b = (long long)blockIdx.x * kEntThreads + threadIdx.x;
+    const bool active = b < g.totalBlocks;
+    long long m = 0;
+    int k = 0, c = 0, padBits = 0, pred = 0;
+    u32 leadMarker = 0;
+    bool tailEoi = false;
+    u64 pos = 0;
+    u32 w[32];
+    if (active) {
+        // Coefficients first: their latency overlaps the offset arithmetic and the barriers.
+        load_block(coef, b, w);
+        m = b / g.bpm;
+        k = (int)(b - m * g.bpm);
+        c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
+        pred = dc_predictor(g, coef, b, m, k, c);
         const long long iv = m / g.mcusPerInterval;
         const long long ivFirstBlock = iv * blocksPerInterval;
-        const u64 pos = ivOff[iv] * 8 + (bitOff[b] - bitOff[ivFirstBlock]);
-        u32 w[32];
-        load_block(coef, b, w);
-        const int pred = dc_predictor(g, coef, b, m, k, c);
-        const int t = c == 0 ? 0 : 1;
-        EmitVisitor vis{tab + 256 * t, tab + 512 + 256 * t, words, (long long)(pos >> 5), 0, (int)(pos & 31), true};
-        walk_block(w, pred, vis);
-        // Last block of an interval: pad to the byte boundary.  Zero padding is what the
-        // reference does (BitBuffer.cpp:12-16) and needs no write.
-        if (g.padOnes) {
-            long long last = ivFirstBlock + blocksPerInterval;
-            if (last > g.totalBlocks) last = g.totalBlocks;
-            if (b == last - 1) {
-                const int rem = vis.n & 7;   // 32-bit words keep byte alignment
-                if (rem != 0) vis.put((1u << (8 - rem)) - 1u, 8 - rem);
+        const int mk = interval_marker_bytes(g, iv);
+        u64 end;
+        if (b == ivFirstBlock) {
+            pos = ivOff[iv] * 8;
+            end = pos + 8 * mk + (bitOff[b + 1] - bitOff[b]);
+            if (mk) leadMarker = 0xffd0u + (u32)((g.firstInterval + iv - 1) & 7);
+        } else {
+            pos = (ivOff[iv] + mk) * 8 + (bitOff[b] - bitOff[ivFirstBlock]);
+            end = pos + (bitOff[b + 1] - bitOff[b]);
+        }
+        long long last = ivFirstBlock + blocksPerInterval;
+        if (last > g.totalBlocks) last = g.totalBlocks;
+        if (b == last - 1) {   // pad the interval to a byte boundary (BitBuffer.cpp:12-16)
+            padBits = (int)((8 - (end & 7)) & 7);
+            end += padBits;
+            if (b == g.totalBlocks - 1 && g.writeEoi) {
+                tailEoi = true;
+                end += 16;
             }
         }
+        if (threadIdx.x == 0) span[0] = pos;
+        if (threadIdx.x == kEntThreads - 1 || b == g.totalBlocks - 1) span[1] = end;
+    }
+    for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = tables[i];
+    __syncthreads();
+    const u64 wordBase = span[0] >> 5;
+    const u64 nWords = ((span[1] + 31) >> 5) - wordBase;
+    const bool staged = nWords <= (u64)kEmitStageWords;
+    if (staged) {
+        for (u32 i = threadIdx.x; i < (u32)nWords; i += kEntThreads) stage[i] = 0;
+        __syncthreads();
+    }
+    if (active) {
+        const int t = c == 0 ? 0 : 1;
+        EmitVisitor vis{tab + 256 * t,       tab + 512 + 256 * t, staged ? stage : words, staged ? (long long)wordBase : 0,
+                        (long long)(pos >> 5), 0,                  (int)(pos & 31),        true};
+        if (leadMarker) vis.put(leadMarker, 16);
+        walk_block(w, pred, vis);
+        if (padBits != 0) vis.put(g.padOnes ? (1u << padBits) - 1u : 0u, padBits);
+        if (tailEoi) vis.put(0xffd9u, 16);
         vis.finish();
+    }
+    if (staged) {
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < (u32)nWords; i += kEntThreads) {
+            const u32 v = stage[i];
+            if (i == 0 || i == (u32)nWords - 1) {
+                if (v != 0) atomicOr(&words[wordBase + i], v);
+            } else {
+                words[wordBase + i] = v;
+            }
+        }
     }
 }
 
@@ -817,7 +875,43 @@ __device__ __forceinline__ int count_ff(u32 w) {
     return __popc(t & 0x01010101u);
 }
 
-__global__ __launch_bounds__(256) void k_count_ff(const uint4* __restrict__ buf, const u64* __restrict__ result,
+// Is the 0xFF at byte position i (followed by `next`) the first byte of a marker that the
+// bit writer placed in the stream?  Only reached for FF D0..D7 / FF D9 pairs, i.e. rarely.
+__device__ __forceinline__ bool is_marker_ff(const KGeom& g, const u64* __restrict__ ivOff, u64 bytes, u64 i,
+                                             uint8_t next) {
+    if (next == 0xd9) return g.writeEoi && i + 2 == bytes;
+    if (next < 0xd0 || next > 0xd7) return false;
+    long long lo = 0, hi = g.intervals - 1;   // last interval starting at or before i
+    while (lo < hi) {
+        const long long mid = (lo + hi + 1) >> 1;
+        if (ivOff[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    return ivOff[lo] == i && interval_marker_bytes(g, lo) != 0;
+}
+
+// Loads 16 stream bytes (plus one of lookahead) and returns a 16-bit mask of the data bytes
+// equal to 0xFF, i.e. those that need a 0x00 behind them (BitBuffer.cpp:156-161, 171-176,
+// 190-195).  Bytes past the end of the stream are zero.
+__device__ __forceinline__ u32 stuff_mask(const KGeom& g, const uint8_t* __restrict__ buf,
+                                          const u64* __restrict__ ivOff, u64 bytes, long long i0, uint4& q) {
+    q = *(const uint4*)(buf + i0);
+    if (count_ff(q.x) + count_ff(q.y) + count_ff(q.z) + count_ff(q.w) == 0) return 0;
+    const u32 ws[5] = {q.x, q.y, q.z, q.w, (u32)buf[i0 + 16]};
+    u32 mask = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint8_t cur = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
+        const uint8_t nxt = (uint8_t)(ws[(j + 1) >> 2] >> (((j + 1) & 3) * 8));
+        if (cur == 0xff && (u64)(i0 + j) < bytes) {
+            const bool maybe = (nxt >= 0xd0 && nxt <= 0xd7) || nxt == 0xd9;
+            if (!(maybe && is_marker_ff(g, ivOff, bytes, (u64)(i0 + j), nxt))) mask |= 1u << j;
+        }
+    }
+    return mask;
+}
+
+__global__ __launch_bounds__(256) void k_count_ff(KGeom g, const uint8_t* __restrict__ buf,
+                                                  const u64* __restrict__ ivOff, const u64* __restrict__ result,
                                                   u32* __restrict__ ffCount) {
     __shared__ u64 lds[4];
     const u64 bytes = result[2];
@@ -826,9 +920,8 @@ __global__ __launch_bounds__(256) void k_count_ff(const uint4* __restrict__ buf,
         const long long i0 = ch * kStuffChunk + (long long)threadIdx.x * 16;
         int cnt = 0;
         if ((u64)i0 < bytes) {
-            const uint4 v = buf[i0 / 16];
-            // Bytes past the end are zero (cleared), so they never count.
-            cnt = count_ff(v.x) + count_ff(v.y) + count_ff(v.z) + count_ff(v.w);
+            uint4 q;
+            cnt = __popc(stuff_mask(g, buf, ivOff, bytes, i0, q));
         }
         u64 total;
         block_exclusive_scan((u64)cnt, lds, total);
@@ -841,85 +934,65 @@ __global__ void k_publish_chunks(u64* __restrict__ result, u64* __restrict__ nCh
     *nChunks = (result[2] + kStuffChunk - 1) / kStuffChunk;
 }
 
-// Markers in front of the first x intervals of the band.
-__device__ __forceinline__ long long markers_before(const KGeom& g, long long x) {
-    return g.firstInterval > 0 ? x : (x > 0 ? x - 1 : 0);
-}
+// Copies the stream to the output with the stuffing bytes inserted.  A workgroup's 4 KiB
+// chunk becomes one contiguous output range, which is laid out in LDS at the output's own
+// 4-byte phase and stored as dwords.
+constexpr int kStuffStageBytes = 2 * kStuffChunk + 16;
 
 __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __restrict__ buf,
                                                      const u64* __restrict__ ivOff, const u64* __restrict__ ffOff,
                                                      u64* __restrict__ result, uint8_t* __restrict__ out,
-                                                     long long prefixLen, long long outCapacity, int writeEoi) {
+                                                     long long prefixLen, long long outCapacity) {
     __shared__ u64 lds[4];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStuffStageBytes];
     const u64 bytes = result[2];
     const long long chunks = (long long)((bytes + kStuffChunk - 1) / kStuffChunk);
     for (long long ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
-        const long long i0 = ch * kStuffChunk + (long long)threadIdx.x * 16;
-        uint8_t v[16];
-        int cnt = 0;
+        const long long c0 = ch * kStuffChunk;
+        const long long i0 = c0 + (long long)threadIdx.x * 16;
+        uint4 q = make_uint4(0, 0, 0, 0);
         int valid = 0;
+        u32 mask = 0;
         if ((u64)i0 < bytes) {
             valid = (int)(bytes - (u64)i0 < 16 ? bytes - (u64)i0 : 16);
-            const uint4 q = *(const uint4*)(buf + i0);
-            const u32 ws[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
-            for (int j = 0; j < valid; ++j) cnt += v[j] == 0xff;
+            mask = stuff_mask(g, buf, ivOff, bytes, i0, q);
         }
+        const long long base = prefixLen + c0 + (long long)ffOff[ch];
         u64 total;
-        const u64 localFf = block_exclusive_scan((u64)cnt, lds, total);
-        if (valid > 0) {
-            // Interval that contains byte i0.
-            long long lo = 0, hi = g.intervals - 1;
-            while (lo < hi) {
-                const long long mid = (lo + hi + 1) >> 1;
-                if (ivOff[mid] <= (u64)i0) lo = mid; else hi = mid - 1;
-            }
-            long long iv = lo;
-            const bool atStart = ivOff[iv] == (u64)i0;
-            long long pos = prefixLen + i0 + (long long)(ffOff[ch] + localFf) +
-                            2 * markers_before(g, atStart ? iv : iv + 1);
-            u64 nextStart = atStart ? (u64)i0 : ivOff[iv + 1];
-            if (!atStart) ++iv;   // iv now names the next interval to start
-            bool overflow = false;
-            for (int j = 0; j < valid; ++j) {
-                if ((u64)(i0 + j) == nextStart) {
-                    const long long gi = g.firstInterval + iv;
-                    if (gi > 0) {   // RSTn in front of every interval but the image's first
-                        if (pos + 2 <= outCapacity) {
-                            out[pos] = 0xff;
-                            out[pos + 1] = (uint8_t)(0xd0 + ((gi - 1) & 7));
-                        } else {
-                            overflow = true;
-                        }
-                        pos += 2;
-                    }
-                    ++iv;
-                    nextStart = iv <= g.intervals - 1 ? ivOff[iv] : ~0ull;
-                }
-                const int extra = v[j] == 0xff ? 2 : 1;   // BitBuffer.cpp:156-161, 171-176, 190-195
-                if (pos + extra <= outCapacity) {
-                    out[pos] = v[j];
-                    if (extra == 2) out[pos + 1] = 0x00;
+        const u64 local = block_exclusive_scan((u64)(valid + __popc(mask)), lds, total);
+        if (base + (long long)total > outCapacity) {
+            if (threadIdx.x == 0) result[1] = 1;
+        } else {
+            const int phase = (int)((uintptr_t)(out + base) & 3);
+            if (valid > 0) {
+                uint8_t* dst = stage + phase + (int)local;
+                if (mask == 0 && valid == 16) {
+                    // Common case: plain copy; unaligned in LDS, so go by bytes.
+                    const u32 ws[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) dst[j] = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
                 } else {
-                    overflow = true;
-                }
-                pos += extra;
-            }
-            if ((u64)(i0 + valid) == bytes) {   // this thread wrote the last scan byte
-                if (writeEoi) {
-                    if (pos + 2 <= outCapacity) {
-                        out[pos] = 0xff;
-                        out[pos + 1] = 0xd9;
-                    } else {
-                        overflow = true;
+                    const u32 ws[4] = {q.x, q.y, q.z, q.w};
+                    int o = 0;
+                    for (int j = 0; j < valid; ++j) {
+                        dst[o++] = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
+                        if ((mask >> j) & 1) dst[o++] = 0x00;
                     }
-                    pos += 2;
                 }
-                result[0] = (u64)pos;
             }
-            if (overflow) result[1] = 1;
+            __syncthreads();
+            const int nTot = phase + (int)total;
+            uint8_t* dst = out + base - phase;   // 4-byte aligned
+            for (int d = threadIdx.x; d * 4 < nTot; d += 256) {
+                const int lo4 = d * 4;
+                if (lo4 >= phase && lo4 + 4 <= nTot) {
+                    *(u32*)(dst + lo4) = *(const u32*)(stage + lo4);
+                } else {
+                    for (int bb = lo4 < phase ? phase : lo4; bb < lo4 + 4 && bb < nTot; ++bb) dst[bb] = stage[bb];
+                }
+            }
         }
+        if (ch == chunks - 1 && threadIdx.x == 0) result[0] = (u64)(base + (long long)total);
         __syncthreads();
     }
 }
@@ -937,14 +1010,15 @@ hipError_t launch_entropy(const KGeom& g, const int16_t* d_coef, const u32* d_ta
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_prepare_unstuffed, dim3(1024), dim3(256), 0, s, ws.ivOff, g.intervals, (uint4*)ws.unstuffed,
                        ws.unstuffedCap, ws.result);
-    hipLaunchKernelGGL(k_emit_bits, dim3((unsigned)grid), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.bitOff,
+    const long long emitGrid = (g.totalBlocks + kEntThreads - 1) / kEntThreads;
+    hipLaunchKernelGGL(k_emit_bits, dim3((unsigned)emitGrid), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.bitOff,
                        ws.ivOff, (u32*)ws.unstuffed);
-    hipLaunchKernelGGL(k_count_ff, dim3(1024), dim3(256), 0, s, (const uint4*)ws.unstuffed, ws.result, ws.ffCount);
+    hipLaunchKernelGGL(k_count_ff, dim3(2048), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.result, ws.ffCount);
     hipLaunchKernelGGL(k_publish_chunks, dim3(1), dim3(1), 0, s, ws.result, ws.result + 3);
     e = exclusive_scan<u32>(ws.ffCount, 0, ws.result + 3, ws.maxChunks, ws.scanTmp, ws.ffOff, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_stuff_bytes, dim3(1024), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.ffOff, ws.result,
-                       d_out, prefixLen, outCapacity, writeEoi);
+    hipLaunchKernelGGL(k_stuff_bytes, dim3(2048), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.ffOff, ws.result,
+                       d_out, prefixLen, outCapacity);
     return hipGetLastError();
 }
 
