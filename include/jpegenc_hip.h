@@ -178,6 +178,12 @@ int jpeg_hip_get_huffman(jpeg_hip_ctx* ctx, uint8_t lengths[4][256], uint16_t co
  * the band does not start the image) to d_out.  *out_len receives its length. */
 int jpeg_hip_emit_scan(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t out_capacity, int64_t* out_len);
 
+/* Same for a host buffer.  The scan is produced once into a device buffer owned by the
+ * context and kept until the coefficients or tables change; *out_len always receives its
+ * length.  With h_out == NULL nothing is copied (size query); a too small buffer returns
+ * JPEG_HIP_ERR_BUFFER_TOO_SMALL. */
+int jpeg_hip_emit_scan_host(jpeg_hip_ctx* ctx, uint8_t* h_out, int64_t out_capacity, int64_t* out_len);
+
 /* Quantized coefficients of one channel copied to the host: blocks in the channel's MCU
  * order (Encoder::createBlocks), 64 zig-zag ordered int16 per block -- the values
  * Encoder::calculateDCValues/ACValues read (Encoder.cpp:268-269, 308-309). */

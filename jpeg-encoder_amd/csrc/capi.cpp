@@ -125,6 +125,7 @@ struct jpeg_hip_ctx {
     Geometry geo;
     KGeom kg;
     bool begun = false, hasPixels = false, transformed = false, hasTables = false;
+    int64_t stagedScanLen = -1;   // scan of the current coefficients and tables held in `staging`, or -1
     const void* rgb = nullptr;
     int fmt = JPEG_HIP_RGB8;
     int64_t stride = 0;
@@ -247,6 +248,7 @@ int install_tables(jpeg_hip_ctx* ctx) {
     HIP_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->pin->tables, sizeof ctx->pin->tables, hipMemcpyHostToDevice,
                                 ctx->stream));
     ctx->hasTables = true;
+    ctx->stagedScanLen = -1;
     return JPEG_HIP_OK;
 }
 
@@ -297,6 +299,7 @@ int do_transform(jpeg_hip_ctx* ctx, int stages) {
     HIP_TRY(ctx, launch_transform(ctx->kg, ctx->rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, ctx->stream));
     mark(ctx, 1);
     ctx->transformed = true;
+    ctx->stagedScanLen = -1;
     return JPEG_HIP_OK;
 }
 
@@ -544,6 +547,28 @@ int jpeg_hip_emit_scan(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t out_capacity, 
     return run_entropy(ctx, d_out, 0, out_capacity, 0, out_len);
 }
 
+int jpeg_hip_emit_scan_host(jpeg_hip_ctx* ctx, uint8_t* h_out, int64_t out_capacity, int64_t* out_len) {
+    if (!ctx || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->transformed || !ctx->hasTables) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "emit needs coefficients and tables");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->stagedScanLen < 0) {
+        jpeg_hip_layout lay;
+        int st = jpeg_hip_compute_layout(&ctx->prm, &lay);
+        if (st != JPEG_HIP_OK) return st;
+        HIP_TRY(ctx, ctx->staging.ensure((size_t)lay.max_jpeg_bytes));
+        int64_t n = 0;
+        st = run_entropy(ctx, (uint8_t*)ctx->staging.p, 0, lay.max_jpeg_bytes, 0, &n);
+        if (st != JPEG_HIP_OK) return st;
+        ctx->stagedScanLen = n;
+    }
+    *out_len = ctx->stagedScanLen;
+    if (!h_out) return JPEG_HIP_OK;
+    if (out_capacity < ctx->stagedScanLen) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "host scan buffer too small");
+    HIP_TRY(ctx, hipMemcpyAsync(h_out, ctx->staging.p, (size_t)ctx->stagedScanLen, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_HIP_OK;
+}
+
 int jpeg_hip_get_coefficients(jpeg_hip_ctx* ctx, int channel, int16_t* h_out, int64_t capacity_values) {
     if (!ctx || !h_out || channel < 0 || channel > 2) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (!ctx->transformed) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "no coefficients yet");
@@ -612,6 +637,7 @@ int jpeg_hip_encode_host(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format
     st = jpeg_hip_compute_layout(params, &lay);
     if (st != JPEG_HIP_OK) return st;
     HIP_TRY(ctx, ctx->staging.ensure((size_t)lay.max_jpeg_bytes));
+    ctx->stagedScanLen = -1;
     int64_t len = 0;
     st = jpeg_hip_finish_band(ctx, (const uint64_t*)ctx->hist.p, (uint8_t*)ctx->staging.p, lay.max_jpeg_bytes, &len);
     if (st != JPEG_HIP_OK) return st;

@@ -21,7 +21,8 @@ EXPORTS = [
     "jpeg_hip_compute_layout", "jpeg_hip_encode", "jpeg_hip_encode_host", "jpeg_hip_begin", "jpeg_hip_upload_pixels",
     "jpeg_hip_bind_pixels", "jpeg_hip_transform", "jpeg_hip_histograms", "jpeg_hip_histograms_host",
     "jpeg_hip_huffman_from_histogram", "jpeg_hip_write_dht", "jpeg_hip_write_headers", "jpeg_hip_set_huffman",
-    "jpeg_hip_build_huffman", "jpeg_hip_get_huffman", "jpeg_hip_emit_scan", "jpeg_hip_get_coefficients",
+    "jpeg_hip_build_huffman", "jpeg_hip_get_huffman", "jpeg_hip_emit_scan", "jpeg_hip_emit_scan_host",
+    "jpeg_hip_get_coefficients",
     "jpeg_hip_coefficients_device", "jpeg_hip_analyze_band", "jpeg_hip_finish_band", "jpeg_hip_set_profiling",
     "jpeg_hip_get_timings",
 ]
@@ -89,6 +90,7 @@ def lib():
         L.jpeg_hip_build_huffman.argtypes = [vp, vp]
         L.jpeg_hip_get_huffman.argtypes = [vp, vp, vp]
         L.jpeg_hip_emit_scan.argtypes = [vp, vp, i64, C.POINTER(i64)]
+        L.jpeg_hip_emit_scan_host.argtypes = [vp, vp, i64, C.POINTER(i64)]
         L.jpeg_hip_get_coefficients.argtypes = [vp, i32, vp, i64]
         L.jpeg_hip_coefficients_device.argtypes = [vp]
         L.jpeg_hip_coefficients_device.restype = vp
@@ -257,6 +259,13 @@ class Context:
         n = C.c_int64(0)
         self._check(lib().jpeg_hip_emit_scan(self._h, C.c_void_p(d_out), capacity, C.byref(n)))
         return n.value
+
+    def emit_scan_host(self):
+        n = C.c_int64(0)
+        self._check(lib().jpeg_hip_emit_scan_host(self._h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.uint8)
+        self._check(lib().jpeg_hip_emit_scan_host(self._h, _np(out), out.size, C.byref(n)))
+        return out[:n.value].tobytes()
 
     def coefficients(self, channel, layout):
         n = int(layout.blocks[channel]) * 64
