@@ -33,7 +33,7 @@ typedef uint8_t u8;
 // Constants.  const_math.h:16-41 builds cosines with a triple-angle recursion in
 // double (tolerance 1e-3); SIMD256.h:335-336 turns them into the AAN factors in float.
 // The recursion is restated here and the results are compared with the hex floats the
-// compiled reference holds (checked by orc_constants_ok()).
+// compiled reference holds (tests/test_oracle_kats.py, through orc_constants()).
 // ------------------------------------------------------------------------------------
 const double kTol = 0.001;                       // const_math.h:16
 const double kPi = 3.14159265358979323846;       // M_PI

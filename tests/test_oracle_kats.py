@@ -136,3 +136,15 @@ def test_padding_is_edge_replication():
     b = O.encode(pad, T.SCHEME_420, T.STANDARD_TABLES)
     for c in range(3):
         assert np.array_equal(a.coef[c], b.coef[c])
+
+
+def test_division_replacements_are_exact(tmp_path):
+    # byte/255.0f and value/q (integer q <= 255) as two-term reciprocal products: the fast
+    # kernels rely on these being bit-identical to IEEE division.
+    import subprocess
+    src = os.path.join(os.path.dirname(__file__), "..", "oracle", "tools", "verify_exact_division.c")
+    exe = str(tmp_path / "verify")
+    subprocess.check_call(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-fopenmp", src, "-o", exe, "-lm"])
+    out = subprocess.check_output([exe, "1"], text=True)
+    assert "mismatches=0" in out
+    assert "hi=0x1.010102p-8 lo=-0x1.fdfdfep-33" in out
