@@ -5,8 +5,6 @@
 // the compiler's correctly rounded fp32 division, rounding is v_rndne_f32 (ties to even).
 #include "kernels.h"
 
-#include <cstdlib>
-
 #include "jpegenc_hip.h"
 
 namespace jpeghip {
@@ -269,10 +267,8 @@ __device__ __forceinline__ void finish_block(float (&v)[64], const float* __rest
 constexpr int k420Mcus = 64;
 constexpr int kChromaPitch = 68;   // floats per block in LDS: keeps 16-byte rows, spreads banks
 
-template <int kMinWaves>
-__global__ __launch_bounds__(256, kMinWaves) void k_transform_420(KGeom g, const unsigned char* __restrict__ rgb,
-                                                                  const float* __restrict__ qtab,
-                                                                  int16_t* __restrict__ coef) {
+__global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned char* __restrict__ rgb,
+                                                       const float* __restrict__ qtab, int16_t* __restrict__ coef) {
     __shared__ __attribute__((aligned(16))) float chroma[2 * k420Mcus * kChromaPitch];
     const float* rhi = qtab + 192;
     const float* rlo = qtab + 384;
@@ -285,17 +281,21 @@ __global__ __launch_bounds__(256, kMinWaves) void k_transform_420(KGeom g, const
         float v[64];
         float* cbDst = chroma + ml * kChromaPitch + (q >> 1) * 32 + (q & 1) * 4;
         float* crDst = cbDst + k420Mcus * kChromaPitch;
+        // All sixteen row loads are issued before the first conversion, so one memory
+        // latency is paid per thread instead of one per row.
+        u32 raw[8][6];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) load_row8(rgb, g.strideBytes, x0, y0 + r, interior, g.W, g.rowsAvail, raw[r]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rp = 0; rp < 4; ++rp) {
             float hcb[2][4], hcr[2][4];
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const int r = 2 * rp + rr;
-                u32 raw[6];
-                load_row8(rgb, g.strideBytes, x0, y0 + r, interior, g.W, g.rowsAvail, raw);
                 float cb[8], cr[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) pixel_ycbcr(raw, i, v[8 * r + i], cb[i], cr[i]);
+                for (int i = 0; i < 8; ++i) pixel_ycbcr(raw[r], i, v[8 * r + i], cb[i], cr[i]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {   // (a + b) / 2.0f, SIMD256.h:260-277
                     hcb[rr][j] = (cb[2 * j] + cb[2 * j + 1]) * 0.5f;
@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256, kMinWaves) void k_transform_420(KGeom g, const
             ocr.z = (hcr[0][2] + hcr[1][2]) * 0.5f; ocr.w = (hcr[0][3] + hcr[1][3]) * 0.5f;
             *(float4*)(cbDst + rp * 8) = ocb;
             *(float4*)(crDst + rp * 8) = ocr;
+            __builtin_amdgcn_sched_barrier(0);   // keep the row pairs in order: bounds live registers
         }
         finish_block(v, rhi, rlo, coef + (m * 6 + q) * 64);
     }
@@ -367,11 +368,9 @@ __device__ __forceinline__ void channel_444(const u32 (&raw)[8][6], const float*
     finish_block(v, rhi + 64 * C, rlo + 64 * C, dst);
 }
 
-template <int kMinWaves, bool kRecompute>
-__global__ __launch_bounds__(k444Threads, kMinWaves) void k_transform_444(KGeom g,
-                                                                          const unsigned char* __restrict__ rgb,
-                                                                          const float* __restrict__ qtab,
-                                                                          int16_t* __restrict__ coef) {
+__global__ __launch_bounds__(k444Threads, 3) void k_transform_444(KGeom g, const unsigned char* __restrict__ rgb,
+                                                                  const float* __restrict__ qtab,
+                                                                  int16_t* __restrict__ coef) {
     const float* rhi = qtab + 192;
     const float* rlo = qtab + 384;
     const long long m = (long long)blockIdx.x * k444Threads + threadIdx.x;
@@ -384,19 +383,17 @@ __global__ __launch_bounds__(k444Threads, kMinWaves) void k_transform_444(KGeom 
     for (int r = 0; r < 8; ++r) load_row8(rgb, g.strideBytes, x0, y0 + r, interior, g.W, g.rowsAvail, raw[r]);
     int16_t* dst = coef + m * 3 * 64;
     channel_444<0>(raw, rhi, rlo, dst);
-    if (kRecompute) {   // keep the byte->float conversions from being shared across channels
+    // Hide the raw words from common-subexpression elimination: sharing the 192 converted
+    // floats across the channels would cost 256 registers and two thirds of the occupancy.
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
+    for (int r = 0; r < 8; ++r)
 #pragma unroll
-            for (int d = 0; d < 6; ++d) asm volatile("" : "+v"(raw[r][d]));
-    }
+        for (int d = 0; d < 6; ++d) asm volatile("" : "+v"(raw[r][d]));
     channel_444<1>(raw, rhi, rlo, dst + 64);
-    if (kRecompute) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
+    for (int r = 0; r < 8; ++r)
 #pragma unroll
-            for (int d = 0; d < 6; ++d) asm volatile("" : "+v"(raw[r][d]));
-    }
+        for (int d = 0; d < 6; ++d) asm volatile("" : "+v"(raw[r][d]));
     channel_444<2>(raw, rhi, rlo, dst + 128);
 }
 
@@ -415,25 +412,12 @@ hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qt
                               (g.strideBytes & 3) == 0 && ((uintptr_t)d_rgb & 3) == 0;
     if (bytesAligned && scheme_is(g, 2, 2, JPEG_HIP_AVERAGE)) {
         const long long grid = (g.nMcu + k420Mcus - 1) / k420Mcus;
-        const char* v = getenv("JPEGHIP_VARIANT");
-        if (v && v[0] == '3')
-            hipLaunchKernelGGL(k_transform_420<3>, dim3((unsigned)grid), dim3(256), 0, s, g, (const unsigned char*)d_rgb,
-                               d_qtab, d_coef);
-        else
-            hipLaunchKernelGGL(k_transform_420<2>, dim3((unsigned)grid), dim3(256), 0, s, g, (const unsigned char*)d_rgb,
-                               d_qtab, d_coef);
+        hipLaunchKernelGGL(k_transform_420, dim3((unsigned)grid), dim3(256), 0, s, g, (const unsigned char*)d_rgb, d_qtab,
+                           d_coef);
     } else if (bytesAligned && scheme_is(g, 1, 1, JPEG_HIP_SUBSAMPLING)) {
         const long long grid = (g.nMcu + k444Threads - 1) / k444Threads;
-        const char* v = getenv("JPEGHIP_VARIANT");
-        if (v && v[0] == '3')
-            hipLaunchKernelGGL((k_transform_444<3, true>), dim3((unsigned)grid), dim3(k444Threads), 0, s, g,
-                               (const unsigned char*)d_rgb, d_qtab, d_coef);
-        else if (v && v[0] == '4')
-            hipLaunchKernelGGL((k_transform_444<4, true>), dim3((unsigned)grid), dim3(k444Threads), 0, s, g,
-                               (const unsigned char*)d_rgb, d_qtab, d_coef);
-        else
-            hipLaunchKernelGGL((k_transform_444<2, false>), dim3((unsigned)grid), dim3(k444Threads), 0, s, g,
-                               (const unsigned char*)d_rgb, d_qtab, d_coef);
+        hipLaunchKernelGGL(k_transform_444, dim3((unsigned)grid), dim3(k444Threads), 0, s, g,
+                           (const unsigned char*)d_rgb, d_qtab, d_coef);
     } else {
         const long long grid = (g.totalBlocks + kGenThreads - 1) / kGenThreads;
         hipLaunchKernelGGL(k_transform_generic, dim3((unsigned)grid), dim3(kGenThreads), 0, s, g, d_rgb, d_qtab, d_coef);
