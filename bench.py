@@ -81,8 +81,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        # RCCL ("nccl") with one GPU per rank; BENCH_DIST_BACKEND=gloo lets several ranks share
+        # one GPU when rehearsing the multi-rank path on a single-GPU box.
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if args.gpus != world:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)

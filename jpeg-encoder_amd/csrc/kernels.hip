@@ -259,6 +259,100 @@ __device__ __forceinline__ void finish_block(float (&v)[64], const float* __rest
     for (int i = 0; i < 8; ++i) dst[i] = make_uint4(packed[4 * i], packed[4 * i + 1], packed[4 * i + 2], packed[4 * i + 3]);
 }
 
+// Same as finish_block, but the wave's 64 blocks go through LDS so that every store
+// instruction writes whole 128-byte lines (8 lanes per block) instead of 64 scattered
+// 16-byte pieces.  `stage` is this wave's area of kRounds-th of 64 x 144 bytes (the 16
+// bytes of padding per block keep the 16-byte LDS accesses conflict free); with kRounds
+// = 2 the two half waves take turns, which halves the LDS footprint.  blockStride:
+// distance in blocks between the blocks of consecutive lanes in the coefficient buffer;
+// lanes at or beyond `count` hold no block.
+constexpr int kStagePitch = 144;
+
+template <int kRounds>
+__device__ __forceinline__ void finish_block_staged(float (&v)[64], const float* __restrict__ rhi,
+                                                    const float* __restrict__ rlo, unsigned char* stage,
+                                                    int16_t* __restrict__ waveBase, int blockStride, int count) {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = v[i] * 255.0f;   // SIMD256.h:484-494
+    aan2d(v);
+    const int lane = threadIdx.x & 63;
+    constexpr int kPerRound = 64 / kRounds;
+    u32 p[32];
+#pragma unroll
+    for (int z = 0; z < 64; z += 2) {
+        const int a = kZZ[z], b = kZZ[z + 1];
+        const float qa = __builtin_fmaf(v[a], rhi[a], v[a] * rlo[a]) + ROUND_MAGIC;
+        const float qb = __builtin_fmaf(v[b], rhi[b], v[b] * rlo[b]) + ROUND_MAGIC;
+        p[z >> 1] = __builtin_amdgcn_perm(__float_as_uint(qb), __float_as_uint(qa), 0x05040100u);
+    }
+#pragma unroll
+    for (int round = 0; round < kRounds; ++round) {
+        if (kRounds == 1 || lane / kPerRound == round) {
+            uint4* mine = (uint4*)(stage + (lane % kPerRound) * kStagePitch);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mine[i] = make_uint4(p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]);
+        }
+        // Same wave wrote and reads: only the LDS counter has to drain, no barrier.
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 8 / kRounds; ++k) {
+            const int local = 8 * k + (lane >> 3);
+            const int blk = round * kPerRound + local;
+            if (blk < count) {
+                const uint4 t = *(const uint4*)(stage + local * kStagePitch + (lane & 7) * 16);
+                *(uint4*)((unsigned char*)waveBase + (long long)blk * blockStride * 128 + (lane & 7) * 16) = t;
+            }
+        }
+        if (kRounds > 1) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// Luma variant for the 4:2:0 kernel: lane l holds block (l & 3) of the wave's MCU (l >> 2);
+// an MCU's four luma blocks are contiguous (512 bytes), MCUs are six blocks apart.  Two
+// half-wave rounds through a 32-block stage.
+__device__ __forceinline__ void finish_block_staged_y(float (&v)[64], const float* __restrict__ rhi,
+                                                      const float* __restrict__ rlo, unsigned char* stage,
+                                                      int16_t* __restrict__ waveBase, int mcuCount) {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) v[i] = v[i] * 255.0f;   // SIMD256.h:484-494
+    aan2d(v);
+    const int lane = threadIdx.x & 63;
+    u32 p[32];
+#pragma unroll
+    for (int z = 0; z < 64; z += 2) {
+        const int a = kZZ[z], b = kZZ[z + 1];
+        const float qa = __builtin_fmaf(v[a], rhi[a], v[a] * rlo[a]) + ROUND_MAGIC;
+        const float qb = __builtin_fmaf(v[b], rhi[b], v[b] * rlo[b]) + ROUND_MAGIC;
+        p[z >> 1] = __builtin_amdgcn_perm(__float_as_uint(qb), __float_as_uint(qa), 0x05040100u);
+    }
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if ((lane >> 5) == round) {
+            uint4* mine = (uint4*)(stage + (lane & 31) * kStagePitch);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mine[i] = make_uint4(p[4 * i], p[4 * i + 1], p[4 * i + 2], p[4 * i + 3]);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int local = 8 * k + (lane >> 3);          // block within the round, 0..31
+            const int blk = round * 32 + local;             // the lane that produced it
+            const int mcu = blk >> 2;
+            if (mcu < mcuCount) {
+                const uint4 t = *(const uint4*)(stage + local * kStagePitch + (lane & 7) * 16);
+                *(uint4*)((unsigned char*)waveBase + ((long long)mcu * 6 + (blk & 3)) * 128 + (lane & 7) * 16) = t;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // 4:2:0 (SamplingScheme.h:63-66): four threads per 16x16 MCU, one per luma block.  Each
 // thread converts its 64 pixels once, keeps Y in registers and reduces Cb/Cr 2x2 on the
 // fly -- horizontal pairs first, then the two rows, as the in-place passes of
@@ -270,11 +364,16 @@ constexpr int kChromaPitch = 68;   // floats per block in LDS: keeps 16-byte row
 __global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned char* __restrict__ rgb,
                                                        const float* __restrict__ qtab, int16_t* __restrict__ coef) {
     __shared__ __attribute__((aligned(16))) float chroma[2 * k420Mcus * kChromaPitch];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 32 * kStagePitch];
     const float* rhi = qtab + 192;
     const float* rlo = qtab + 384;
     const int tid = threadIdx.x, q = tid & 3, ml = tid >> 2;
-    const long long m = (long long)blockIdx.x * k420Mcus + ml;
-    if (m < g.nMcu) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long mBase = (long long)blockIdx.x * k420Mcus;
+    const long long left = g.nMcu - mBase;
+    const int mcuCount = left < k420Mcus ? (int)left : k420Mcus;   // MCUs of this workgroup that exist
+    const long long m = mBase + (ml < mcuCount ? ml : mcuCount - 1);   // idle lanes redo the last MCU, store nothing
+    {
         const int my = (int)(m / g.mcusPerRow), mx = (int)(m - (long long)my * g.mcusPerRow);
         const int x0 = mx * 16 + (q & 1) * 8, y0 = my * 16 + (q >> 1) * 8;
         const bool interior = x0 + 8 <= g.W && y0 + 8 <= g.rowsAvail;
@@ -311,33 +410,61 @@ __global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned c
             *(float4*)(crDst + rp * 8) = ocr;
             __builtin_amdgcn_sched_barrier(0);   // keep the row pairs in order: bounds live registers
         }
-        finish_block(v, rhi, rlo, coef + (m * 6 + q) * 64);
+        // The wave's 64 luma blocks are 16 MCUs x 4: consecutive lanes, consecutive blocks
+        // inside an MCU, 6 blocks from MCU to MCU.  Lane l's block sits at
+        // (l >> 2) * 6 + (l & 3) blocks from the wave's first; staged stores take a uniform
+        // stride, so the four blocks of an MCU are addressed through their MCU.
+        const int waveMcus = mcuCount - wave * 16;   // MCUs of this wave that exist (may be <= 0)
+        finish_block_staged_y(v, rhi, rlo, stage + wave * 32 * kStagePitch, coef + (mBase + wave * 16) * 6 * 64,
+                              waveMcus);
     }
     __syncthreads();
     if (tid < 2 * k420Mcus) {
-        const int ch = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave 0: Cb, wave 1: Cr
-        const int ml2 = tid & 63;
-        const long long m2 = (long long)blockIdx.x * k420Mcus + ml2;
-        if (m2 < g.nMcu) {
-            const float4* src = (const float4*)(chroma + (ch * k420Mcus + ml2) * kChromaPitch);
-            float v[64];
+        const int ch = wave;   // wave 0: Cb, wave 1: Cr
+        const float4* src = (const float4*)(chroma + (ch * k420Mcus + (tid & 63)) * kChromaPitch);
+        float v[64];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float4 t = src[i];
-                v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
-            }
-            finish_block(v, rhi + 64 * (1 + ch), rlo + 64 * (1 + ch), coef + (m2 * 6 + 4 + ch) * 64);
+        for (int i = 0; i < 16; ++i) {
+            const float4 t = src[i];
+            v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
         }
+        finish_block_staged<2>(v, rhi + 64 * (1 + ch), rlo + 64 * (1 + ch), stage + wave * 32 * kStagePitch,
+                               coef + (mBase * 6 + 4 + ch) * 64, 6, mcuCount);
     }
 }
 
-// 4:4:4 (SamplingScheme.h:48-51): one thread per 8x8 pixel block.  The 192 raw bytes stay
-// in registers; each channel is converted, transformed and stored in turn.
-constexpr int k444Threads = 64;
+// 4:4:4 (SamplingScheme.h:48-51): three waves per workgroup, one per channel, each thread
+// one 8x8 block.  The three waves of a workgroup read the same 64 x 192 pixel bytes (two of
+// them from L1/L2), convert them for their own channel only and transform from registers:
+// no value is shared between channels, so nothing has to be kept or exchanged, the channel
+// is wave-uniform (scalar table loads, no divergence) and a 4K image still fills the chip.
+constexpr int k444Positions = 64;
 
-template <int C>
-__device__ __forceinline__ void channel_444(const u32 (&raw)[8][6], const float* __restrict__ rhi,
-                                            const float* __restrict__ rlo, int16_t* __restrict__ dst) {
+__global__ __launch_bounds__(3 * k444Positions) void k_transform_444(KGeom g, const unsigned char* __restrict__ rgb,
+                                                                     const float* __restrict__ qtab,
+                                                                     int16_t* __restrict__ coef) {
+    const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* rhi = qtab + 192 + 64 * c;
+    const float* rlo = qtab + 384 + 64 * c;
+    // Matrix row of this wave's channel (SIMD256.h:170-175) in scalar registers.  Y's bias
+    // of +0.0f is added like the others: Y is never -0.0, so the sum is unchanged.
+    const float m0 = c == 0 ? 0.2990f : (c == 1 ? -0.1687f : 0.5000f);
+    const float m1 = c == 0 ? 0.5870f : (c == 1 ? -0.3312f : -0.4186f);
+    const float m2 = c == 0 ? 0.1140f : (c == 1 ? 0.5000f : -0.0813f);
+    const float bias = c == 0 ? 0.0f : 0.5f;
+    __shared__ __attribute__((aligned(16))) unsigned char stage[3 * 64 * kStagePitch];
+    const long long m0w = (long long)blockIdx.x * k444Positions;
+    const long long m = m0w + (threadIdx.x & 63);
+    const long long left = g.nMcu - m0w;
+    const int count = left < 64 ? (int)left : 64;
+    const long long mc = m < g.nMcu ? m : g.nMcu - 1;   // idle lanes redo the last block, store nothing
+    const int my = (int)(mc / g.mcusPerRow), mx = (int)(mc - (long long)my * g.mcusPerRow);
+    const int x0 = mx * 8, y0 = my * 8;
+    const bool interior = x0 + 8 <= g.W && y0 + 8 <= g.rowsAvail;
+    u32 raw[8][6];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) load_row8(rgb, g.strideBytes, x0, y0 + r, interior, g.W, g.rowsAvail, raw[r]);
+    __builtin_amdgcn_sched_barrier(0);
     float v[64];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -346,55 +473,14 @@ __device__ __forceinline__ void channel_444(const u32 (&raw)[8][6], const float*
             const float rr = unorm8(raw[r][(3 * i) >> 2], (3 * i) & 3);
             const float gg = unorm8(raw[r][(3 * i + 1) >> 2], (3 * i + 1) & 3);
             const float bb = unorm8(raw[r][(3 * i + 2) >> 2], (3 * i + 2) & 3);
-            float t;
-            if (C == 0) {
-                t = 0.2990f * rr;
-                t = t + 0.5870f * gg;
-                t = t + 0.1140f * bb;
-            } else if (C == 1) {
-                t = -0.1687f * rr;
-                t = t + -0.3312f * gg;
-                t = t + 0.5000f * bb;
-                t = t + 0.5f;
-            } else {
-                t = 0.5000f * rr;
-                t = t + -0.4186f * gg;
-                t = t + -0.0813f * bb;
-                t = t + 0.5f;
-            }
-            v[8 * r + i] = t;
+            float t = m0 * rr;
+            t = t + m1 * gg;
+            t = t + m2 * bb;
+            v[8 * r + i] = t + bias;
         }
+        __builtin_amdgcn_sched_barrier(0);   // row by row: bounds the live registers
     }
-    finish_block(v, rhi + 64 * C, rlo + 64 * C, dst);
-}
-
-__global__ __launch_bounds__(k444Threads, 3) void k_transform_444(KGeom g, const unsigned char* __restrict__ rgb,
-                                                                  const float* __restrict__ qtab,
-                                                                  int16_t* __restrict__ coef) {
-    const float* rhi = qtab + 192;
-    const float* rlo = qtab + 384;
-    const long long m = (long long)blockIdx.x * k444Threads + threadIdx.x;
-    if (m >= g.nMcu) return;
-    const int my = (int)(m / g.mcusPerRow), mx = (int)(m - (long long)my * g.mcusPerRow);
-    const int x0 = mx * 8, y0 = my * 8;
-    const bool interior = x0 + 8 <= g.W && y0 + 8 <= g.rowsAvail;
-    u32 raw[8][6];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) load_row8(rgb, g.strideBytes, x0, y0 + r, interior, g.W, g.rowsAvail, raw[r]);
-    int16_t* dst = coef + m * 3 * 64;
-    channel_444<0>(raw, rhi, rlo, dst);
-    // Hide the raw words from common-subexpression elimination: sharing the 192 converted
-    // floats across the channels would cost 256 registers and two thirds of the occupancy.
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int d = 0; d < 6; ++d) asm volatile("" : "+v"(raw[r][d]));
-    channel_444<1>(raw, rhi, rlo, dst + 64);
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int d = 0; d < 6; ++d) asm volatile("" : "+v"(raw[r][d]));
-    channel_444<2>(raw, rhi, rlo, dst + 128);
+    finish_block_staged<1>(v, rhi, rlo, stage + c * 64 * kStagePitch, coef + (m0w * 3 + c) * 64, 3, count);
 }
 
 static bool scheme_is(const KGeom& g, int wf, int hf, int method) {
@@ -415,8 +501,8 @@ hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qt
         hipLaunchKernelGGL(k_transform_420, dim3((unsigned)grid), dim3(256), 0, s, g, (const unsigned char*)d_rgb, d_qtab,
                            d_coef);
     } else if (bytesAligned && scheme_is(g, 1, 1, JPEG_HIP_SUBSAMPLING)) {
-        const long long grid = (g.nMcu + k444Threads - 1) / k444Threads;
-        hipLaunchKernelGGL(k_transform_444, dim3((unsigned)grid), dim3(k444Threads), 0, s, g,
+        const long long grid = (g.nMcu + k444Positions - 1) / k444Positions;
+        hipLaunchKernelGGL(k_transform_444, dim3((unsigned)grid), dim3(3 * k444Positions), 0, s, g,
                            (const unsigned char*)d_rgb, d_qtab, d_coef);
     } else {
         const long long grid = (g.totalBlocks + kGenThreads - 1) / kGenThreads;
@@ -456,19 +542,29 @@ __device__ __forceinline__ void walk_block(const u32 (&w)[32], int pred, Visitor
     const int dcat = bit_category(diff);
     vis.dc(dcat, (u32)(diff < 0 ? diff - 1 : diff) & ((1u << dcat) - 1u));
     int run = 0;
+    // Eight coefficients (one 16-byte load) at a time: groups that are all zero -- most of
+    // the high-frequency half of a typical block -- only extend the run.
 #pragma unroll
-    for (int i = 1; i < 64; ++i) {
-        const int v = coef_at(w, i);
-        if (v != 0) {
-            if (run > 15) {
-                vis.zrl(run >> 4);
-                run &= 15;
+    for (int grp = 0; grp < 8; ++grp) {
+        const u32 any = (grp == 0 ? (w[0] & 0xffff0000u) : w[4 * grp]) | w[4 * grp + 1] | w[4 * grp + 2] | w[4 * grp + 3];
+        if (any == 0) {
+            run += grp == 0 ? 7 : 8;
+            continue;
+        }
+#pragma unroll
+        for (int i = 8 * grp + (grp == 0 ? 1 : 0); i < 8 * grp + 8; ++i) {
+            const int v = coef_at(w, i);
+            if (v != 0) {
+                if (run > 15) {
+                    vis.zrl(run >> 4);
+                    run &= 15;
+                }
+                const int cat = bit_category(v);
+                vis.ac((run << 4) | cat, cat, (u32)(v < 0 ? v - 1 : v) & ((1u << cat) - 1u));
+                run = 0;
+            } else {
+                ++run;
             }
-            const int cat = bit_category(v);
-            vis.ac((run << 4) | cat, cat, (u32)(v < 0 ? v - 1 : v) & ((1u << cat) - 1u));
-            run = 0;
-        } else {
-            ++run;
         }
     }
     if (run != 0) vis.eob();
@@ -744,15 +840,14 @@ struct EmitVisitor {
         n += len;
         if (n >= 32) flush_word();
     }
+    // Code and amplitude go in together: at most 16 + 11 bits on top of fewer than 32 pending.
     __device__ __forceinline__ void dc(int cat, u32 amp) {
         const u32 e = dcTab[cat];
-        put(e & 0xffffu, (int)(e >> 16));
-        put(amp, cat);
+        put(((e & 0xffffu) << cat) | amp, (int)(e >> 16) + cat);
     }
     __device__ __forceinline__ void ac(int sym, int cat, u32 amp) {
         const u32 e = acTab[sym];
-        put(e & 0xffffu, (int)(e >> 16));
-        put(amp, cat);
+        put(((e & 0xffffu) << cat) | amp, (int)(e >> 16) + cat);
     }
     __device__ __forceinline__ void zrl(int cnt) {
         const u32 e = acTab[0xF0];
