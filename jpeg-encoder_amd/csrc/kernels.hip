@@ -636,24 +636,52 @@ struct LengthVisitor {
     __device__ __forceinline__ void eob() { bits += acTab[0] >> 16; }
 };
 
+// With kTileSums the kernel also produces the per-tile sums (tiles of kScanTile consecutive
+// blocks) that the offset scan starts from, which saves that scan's first pass; a
+// workgroup then owns whole tiles, so this form is for images with many tiles.
+constexpr int kLenTile = 2048;   // == kScanTile
+
+template <bool kTileSums>
 __global__ __launch_bounds__(kEntThreads) void k_bit_lengths(KGeom g, const int16_t* __restrict__ coef,
                                                              const u32* __restrict__ tables,
-                                                             u32* __restrict__ bitLen) {
+                                                             u32* __restrict__ bitLen, u64* __restrict__ tileSums) {
     __shared__ u32 tab[4 * 256];
+    __shared__ u32 partial[kEntThreads / 64];
     for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = tables[i];
     __syncthreads();
-    for (long long b = (long long)blockIdx.x * kEntThreads + threadIdx.x; b < g.totalBlocks;
-         b += (long long)gridDim.x * kEntThreads) {
-        const long long m = b / g.bpm;
-        const int k = (int)(b - m * g.bpm);
-        const int c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
-        u32 w[32];
-        load_block(coef, b, w);
-        const int pred = dc_predictor(g, coef, b, m, k, c);
-        const int t = c == 0 ? 0 : 1;
-        LengthVisitor vis{tab + 256 * t, tab + 512 + 256 * t, 0u};
-        walk_block(w, pred, vis);
-        bitLen[b] = vis.bits;
+    constexpr int kSpan = kTileSums ? kLenTile : kEntThreads;   // blocks per workgroup pass
+    const long long spans = (g.totalBlocks + kSpan - 1) / kSpan;
+    for (long long span = blockIdx.x; span < spans; span += gridDim.x) {
+        u32 sum = 0;
+#pragma unroll 1
+        for (int it = 0; it < kSpan / kEntThreads; ++it) {
+            const long long b = span * kSpan + it * kEntThreads + threadIdx.x;
+            if (b < g.totalBlocks) {
+                const long long m = b / g.bpm;
+                const int k = (int)(b - m * g.bpm);
+                const int c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
+                u32 w[32];
+                load_block(coef, b, w);
+                const int pred = dc_predictor(g, coef, b, m, k, c);
+                const int t = c == 0 ? 0 : 1;
+                LengthVisitor vis{tab + 256 * t, tab + 512 + 256 * t, 0u};
+                walk_block(w, pred, vis);
+                bitLen[b] = vis.bits;
+                sum += vis.bits;
+            }
+        }
+        if (kTileSums) {
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+            if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = sum;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                u64 total = 0;
+                for (int i = 0; i < kEntThreads / 64; ++i) total += partial[i];
+                tileSums[span] = total;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -757,13 +785,49 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const TIn* __restri
     }
 }
 
+// One workgroup scans everything: for short inputs one launch beats three.
+template <typename TIn>
+__global__ __launch_bounds__(kScanThreads) void k_scan_small(const TIn* __restrict__ in, long long nHost,
+                                                             const u64* __restrict__ dN, u64* __restrict__ out) {
+    __shared__ u64 lds[4];
+    const long long n = dN ? (long long)*dN : nHost;
+    u64 carry = 0;
+    for (long long base0 = 0; base0 < n; base0 += kScanTile) {
+        const long long base = base0 + (long long)threadIdx.x * kScanItems;
+        u64 vals[kScanItems];
+        u64 s = 0;
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) {
+            vals[i] = base + i < n ? (u64)in[base + i] : 0;
+            s += vals[i];
+        }
+        u64 total;
+        u64 run = carry + block_exclusive_scan(s, lds, total);
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) {
+            if (base + i < n) out[base + i] = run;
+            run += vals[i];
+        }
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
+constexpr long long kSmallScanLimit = 32768;
+
 template <typename TIn>
 static hipError_t exclusive_scan(const TIn* in, long long nHost, const u64* dN, long long nMax, u64* tmp, u64* out,
-                                 hipStream_t s) {
+                                 hipStream_t s, bool haveTileSums = false) {
+    if (!haveTileSums && nMax <= kSmallScanLimit) {
+        hipLaunchKernelGGL(k_scan_small<TIn>, dim3(1), dim3(kScanThreads), 0, s, in, nHost, dN, out);
+        return hipGetLastError();
+    }
     long long tiles = (nMax + kScanTile - 1) / kScanTile;
     if (tiles < 1) tiles = 1;
     const unsigned grid = (unsigned)(tiles > 1024 ? 1024 : tiles);
-    hipLaunchKernelGGL(k_scan_tile_sums<TIn>, dim3(grid), dim3(kScanThreads), 0, s, in, nHost, dN, tmp);
+    if (!haveTileSums)
+        hipLaunchKernelGGL(k_scan_tile_sums<TIn>, dim3(grid), dim3(kScanThreads), 0, s, in, nHost, dN, tmp);
     hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanThreads), 0, s, nHost, dN, tmp);
     hipLaunchKernelGGL(k_scan_apply<TIn>, dim3(grid), dim3(kScanThreads), 0, s, in, nHost, dN, tmp, out);
     return hipGetLastError();
@@ -789,20 +853,53 @@ __global__ void k_interval_bytes(KGeom g, const u64* __restrict__ bitOff, u64* _
     ivBytes[k] = n;
 }
 
-// Clears the part of the unstuffed buffer the bit writer will OR into and publishes the
-// byte count for the later kernels.
-__global__ void k_prepare_unstuffed(const u64* __restrict__ ivOff, long long intervals, uint4* __restrict__ buf,
-                                    long long capBytes, u64* __restrict__ result) {
+// Interval sizes, their offsets and the stream totals in one launch (one workgroup), for up
+// to kSmallScanLimit intervals.
+__global__ __launch_bounds__(kScanThreads) void k_intervals_small(KGeom g, const u64* __restrict__ bitOff,
+                                                                  u64* __restrict__ ivOff, u64* __restrict__ result) {
+    __shared__ u64 lds[4];
+    const long long perInterval = g.mcusPerInterval * g.bpm;
+    u64 carry = 0;
+    for (long long k0 = 0; k0 < g.intervals; k0 += kScanThreads) {
+        const long long k = k0 + threadIdx.x;
+        u64 n = 0;
+        if (k < g.intervals) {
+            const long long b0 = k * perInterval;
+            long long b1 = b0 + perInterval;
+            if (b1 > g.totalBlocks) b1 = g.totalBlocks;
+            n = ((bitOff[b1] - bitOff[b0] + 7) >> 3) + interval_marker_bytes(g, k);
+            if (k == g.intervals - 1 && g.writeEoi) n += 2;
+        }
+        u64 total;
+        const u64 ex = block_exclusive_scan(n, lds, total);
+        if (k < g.intervals) ivOff[k] = carry + ex;
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        ivOff[g.intervals] = carry;
+        result[2] = carry;
+        result[1] = 0;
+        result[3] = (carry + kStuffChunk - 1) / kStuffChunk;
+    }
+}
+
+// Totals for the general path (many intervals), after the interval offsets were scanned.
+__global__ void k_publish_totals(const u64* __restrict__ ivOff, long long intervals, u64* __restrict__ result) {
     const u64 bytes = ivOff[intervals];
+    result[2] = bytes;
+    result[1] = 0;
+    result[3] = (bytes + kStuffChunk - 1) / kStuffChunk;
+}
+
+// Clears the part of the unstuffed buffer the bit writer will OR into.
+__global__ void k_prepare_unstuffed(const u64* __restrict__ result, uint4* __restrict__ buf, long long capBytes) {
+    const u64 bytes = result[2];
     long long clear = (long long)((bytes + kStuffChunk - 1) / kStuffChunk) * kStuffChunk + 16;
     if (clear > capBytes) clear = capBytes;
     const long long n16 = clear / 16;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x)
         buf[i] = make_uint4(0, 0, 0, 0);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        result[2] = bytes;
-        result[1] = 0;
-    }
 }
 
 // ---- bit writer ------------------------------------------------------------------------
@@ -1009,10 +1106,6 @@ __global__ __launch_bounds__(256) void k_count_ff(KGeom g, const uint8_t* __rest
     }
 }
 
-__global__ void k_publish_chunks(u64* __restrict__ result, u64* __restrict__ nChunks) {
-    *nChunks = (result[2] + kStuffChunk - 1) / kStuffChunk;
-}
-
 // Copies the stream to the output with the stuffing bytes inserted.  A workgroup's 4 KiB
 // chunk becomes one contiguous output range, which is laid out in LDS at the output's own
 // 4-byte phase and stored as dwords.
@@ -1078,26 +1171,46 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
 
 hipError_t launch_entropy(const KGeom& g, const int16_t* d_coef, const u32* d_tables, const EntropyWorkspace& ws,
                           uint8_t* d_out, long long prefixLen, long long outCapacity, int writeEoi, hipStream_t s) {
-    long long grid = (g.totalBlocks + kEntThreads - 1) / kEntThreads;
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_bit_lengths, dim3((unsigned)grid), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.bitLen);
-    hipError_t e = exclusive_scan<u32>(ws.bitLen, g.totalBlocks, nullptr, g.totalBlocks, ws.scanTmp, ws.bitOff, s);
+    (void)writeEoi;   // carried in g.writeEoi
+    const long long tiles = (g.totalBlocks + kLenTile - 1) / kLenTile;
+    const bool fusedSums = tiles >= 1024;   // enough tiles to fill the chip with whole-tile workgroups
+    hipError_t e;
+    if (fusedSums) {
+        const unsigned lenGrid = (unsigned)(tiles > 2048 ? 2048 : tiles);
+        hipLaunchKernelGGL(k_bit_lengths<true>, dim3(lenGrid), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.bitLen,
+                           ws.scanTmp);
+    } else {
+        long long lenGrid = (g.totalBlocks + kEntThreads - 1) / kEntThreads;
+        if (lenGrid > 4096) lenGrid = 4096;
+        hipLaunchKernelGGL(k_bit_lengths<false>, dim3((unsigned)lenGrid), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
+                           ws.bitLen, ws.scanTmp);
+    }
+    e = exclusive_scan<u32>(ws.bitLen, g.totalBlocks, nullptr, g.totalBlocks, ws.scanTmp, ws.bitOff, s, fusedSums);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_interval_bytes, dim3((unsigned)((g.intervals + 255) / 256)), dim3(256), 0, s, g, ws.bitOff,
-                       ws.ivBytes);
-    e = exclusive_scan<u64>(ws.ivBytes, g.intervals, nullptr, g.intervals, ws.scanTmp, ws.ivOff, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_prepare_unstuffed, dim3(1024), dim3(256), 0, s, ws.ivOff, g.intervals, (uint4*)ws.unstuffed,
-                       ws.unstuffedCap, ws.result);
+    if (g.intervals <= kSmallScanLimit) {
+        hipLaunchKernelGGL(k_intervals_small, dim3(1), dim3(kScanThreads), 0, s, g, ws.bitOff, ws.ivOff, ws.result);
+    } else {
+        hipLaunchKernelGGL(k_interval_bytes, dim3((unsigned)((g.intervals + 255) / 256)), dim3(256), 0, s, g, ws.bitOff,
+                           ws.ivBytes);
+        e = exclusive_scan<u64>(ws.ivBytes, g.intervals, nullptr, g.intervals, ws.scanTmp, ws.ivOff, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_publish_totals, dim3(1), dim3(1), 0, s, ws.ivOff, g.intervals, ws.result);
+    }
+    long long zeroGrid = ws.unstuffedCap / (16 * 256 * 8);
+    zeroGrid = zeroGrid < 1 ? 1 : (zeroGrid > 1024 ? 1024 : zeroGrid);
+    hipLaunchKernelGGL(k_prepare_unstuffed, dim3((unsigned)zeroGrid), dim3(256), 0, s, ws.result, (uint4*)ws.unstuffed,
+                       ws.unstuffedCap);
     const long long emitGrid = (g.totalBlocks + kEntThreads - 1) / kEntThreads;
     hipLaunchKernelGGL(k_emit_bits, dim3((unsigned)emitGrid), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.bitOff,
                        ws.ivOff, (u32*)ws.unstuffed);
-    hipLaunchKernelGGL(k_count_ff, dim3(2048), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.result, ws.ffCount);
-    hipLaunchKernelGGL(k_publish_chunks, dim3(1), dim3(1), 0, s, ws.result, ws.result + 3);
+    long long chunkGrid = ws.maxChunks < 2048 ? ws.maxChunks : 2048;
+    if (chunkGrid < 1) chunkGrid = 1;
+    hipLaunchKernelGGL(k_count_ff, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.result,
+                       ws.ffCount);
     e = exclusive_scan<u32>(ws.ffCount, 0, ws.result + 3, ws.maxChunks, ws.scanTmp, ws.ffOff, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_stuff_bytes, dim3(2048), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.ffOff, ws.result,
-                       d_out, prefixLen, outCapacity);
+    hipLaunchKernelGGL(k_stuff_bytes, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.ffOff,
+                       ws.result, d_out, prefixLen, outCapacity);
     return hipGetLastError();
 }
 
