@@ -45,6 +45,15 @@ def algorithmic_bytes(lay):
     return 3 * px + 2 * 64 * int(lay.total_blocks)
 
 
+def measured_traffic(workload, world):
+    """HBM bytes per launch of the fused transform from the committed PMC passes (N=1 only)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    entry = json.load(open(path)).get(workload)
+    return entry["traffic_bytes_per_launch"] if entry else None
+
+
 def cpu_baseline(width, height, scheme, qt, kind):
     """The CPU oracle (a port of the reference path) timed on a bounded crop of the workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -173,7 +182,8 @@ def main():
                        "parallelism": "band-per-gpu x%d" % world, "jpeg_bytes_rank0": int(n_out)},
             "roofline": {"bound": "hbm", "kernel": "fused transform (colour, subsample, DCT, quantize, zig-zag)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": measured_traffic(args.workload, world),
                          "algorithmic_bytes_per_launch": int(alg), "kernel_ms": round(float(kern_ms[0]), 4)},
             "stage_ms": {"transform": round(float(kern_ms[0]), 4), "histogram": round(float(kern_ms[1]), 4),
                          "entropy": round(float(kern_ms[2]), 4), "host_tables": round(float(kern_ms[3]), 4)},
