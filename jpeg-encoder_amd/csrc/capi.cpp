@@ -199,6 +199,10 @@ void fill_kgeom(jpeg_hip_ctx* ctx) {
     k.firstInterval = g.firstInterval;
     k.padOnes = ctx->prm.pad_ones ? 1 : 0;
     k.writeEoi = 0;
+    k.batch = 1;
+    k.mcusPerImage = g.nMcu;
+    k.blocksPerImage = g.totalBlocks;
+    k.imageStrideBytes = 0;
 }
 
 int ensure_workspace(jpeg_hip_ctx* ctx) {

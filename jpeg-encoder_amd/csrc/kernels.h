@@ -27,6 +27,24 @@ struct KGeom {
     long long firstInterval;     // global index of the band's first interval
     int padOnes;
     int writeEoi;                // the band ends the image: EOI follows its last interval
+    // Batch of equally shaped images encoded in one pass: image i occupies MCUs
+    // [i * mcusPerImage, (i + 1) * mcusPerImage), its pixels start imageStrideBytes after the
+    // previous image's, and every image is one interval with its own tables and EOI.
+    int batch;
+    long long mcusPerImage;
+    long long blocksPerImage;
+    long long imageStrideBytes;
+};
+
+// Where a batch's files go: slot i starts at out + i * slotBytes and receives header i
+// (hdrLen[i] bytes from hdr + i * hdrPitch) followed by the image's scan and EOI.
+struct BatchOutput {
+    uint8_t* out;
+    long long slotBytes;
+    const uint8_t* hdr;
+    const uint32_t* hdrLen;
+    int hdrPitch;
+    unsigned long long* ffStart;   // [batch + 1]: stuffing bytes in front of each image's stream
 };
 
 // Device workspace of the entropy stage (all sizes fixed by the geometry).
@@ -49,7 +67,7 @@ constexpr int kStuffChunk = 4096;   // unstuffed bytes handled by one workgroup 
 // Fused colour conversion + subsampling + DCT + quantization + zig-zag.
 hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef, hipStream_t s);
 
-// Symbol histograms (uint64[4][256]); d_hist is cleared first.
+// Symbol histograms (uint64[4][256] per image of the batch); d_hist is cleared first.
 hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, unsigned long long* d_hist, hipStream_t s);
 
 // Bit lengths, offsets, bit writer and byte stuffing.  d_tables: uint32[4][256], entry =
@@ -58,6 +76,12 @@ hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, unsigned long
 // ws.result[1] is non-zero when outCapacity was too small.
 hipError_t launch_entropy(const KGeom& g, const int16_t* d_coef, const uint32_t* d_tables, const EntropyWorkspace& ws,
                           uint8_t* d_out, long long prefixLen, long long outCapacity, int writeEoi, hipStream_t s);
+
+// Batch form: d_tables holds one table set per image (uint32[batch][4][256]), the output
+// goes to the slots of `bo`.  ws.result[1] is non-zero when a slot was too small; the
+// per-image lengths follow from ws.ivOff, bo.ffStart and the header lengths.
+hipError_t launch_entropy_batch(const KGeom& g, const int16_t* d_coef, const uint32_t* d_tables,
+                                const EntropyWorkspace& ws, const BatchOutput& bo, hipStream_t s);
 
 }  // namespace jpeghip
 

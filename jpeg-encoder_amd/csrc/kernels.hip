@@ -99,6 +99,19 @@ __device__ __forceinline__ void load_pixel(const void* rgb, long long stride, in
     }
 }
 
+// MCU m of the pass -> MCU position inside its image and that image's pixels.
+__device__ __forceinline__ long long locate_mcu(const KGeom& g, long long m, int& mx, int& my) {
+    long long ml = m, offset = 0;
+    if (g.batch > 1) {
+        const long long img = m / g.mcusPerImage;
+        ml = m - img * g.mcusPerImage;
+        offset = img * g.imageStrideBytes;
+    }
+    my = (int)(ml / g.mcusPerRow);
+    mx = (int)(ml - (long long)my * g.mcusPerRow);
+    return offset;
+}
+
 // Which channel a block of an MCU belongs to, and its position inside the MCU
 // (Encoder::createBlocks, Encoder.cpp:202-223; scan order of Encoder.cpp:500-514).
 __device__ __forceinline__ void block_in_mcu(const KGeom& g, int k, int& c, int& bx, int& by) {
@@ -130,7 +143,8 @@ __global__ __launch_bounds__(kGenThreads) void k_transform_generic(KGeom g, cons
     const int k = (int)(b - m * g.bpm);
     int c, bx, by;
     block_in_mcu(g, k, c, bx, by);
-    const int my = (int)(m / g.mcusPerRow), mx = (int)(m - (long long)my * g.mcusPerRow);
+    int mx, my;
+    const unsigned char* pix = (const unsigned char*)rgb + locate_mcu(g, m, mx, my);
     const int X0 = (mx * g.hF[c] + bx) * 8, Y0 = (my * g.vF[c] + by) * 8;
     const int wf = g.wf[c], hf = g.hf[c];
     const int nw = g.wm[c] == JPEG_HIP_AVERAGE ? wf : 1;
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(kGenThreads) void k_transform_generic(KGeom g, cons
             for (int dx = 0; dx < nw; ++dx) {
                 const int sx = min(sx0 + dx, g.W - 1);
                 float r, gg, bb;
-                load_pixel(rgb, g.strideBytes, g.sampleFormat, sx, sy, r, gg, bb);
+                load_pixel(pix, g.strideBytes, g.sampleFormat, sx, sy, r, gg, bb);
                 const float v = channel_value(c, convert, r, gg, bb);
                 hsum = dx == 0 ? v : hsum + v;
             }
@@ -374,7 +388,8 @@ __global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned c
     const int mcuCount = left < k420Mcus ? (int)left : k420Mcus;   // MCUs of this workgroup that exist
     const long long m = mBase + (ml < mcuCount ? ml : mcuCount - 1);   // idle lanes redo the last MCU, store nothing
     {
-        const int my = (int)(m / g.mcusPerRow), mx = (int)(m - (long long)my * g.mcusPerRow);
+        int mx, my;
+        rgb += locate_mcu(g, m, mx, my);
         const int x0 = mx * 16 + (q & 1) * 8, y0 = my * 16 + (q >> 1) * 8;
         const bool interior = x0 + 8 <= g.W && y0 + 8 <= g.rowsAvail;
         float v[64];
@@ -458,7 +473,8 @@ __global__ __launch_bounds__(3 * k444Positions) void k_transform_444(KGeom g, co
     const long long left = g.nMcu - m0w;
     const int count = left < 64 ? (int)left : 64;
     const long long mc = m < g.nMcu ? m : g.nMcu - 1;   // idle lanes redo the last block, store nothing
-    const int my = (int)(mc / g.mcusPerRow), mx = (int)(mc - (long long)my * g.mcusPerRow);
+    int mx, my;
+    rgb += locate_mcu(g, mc, mx, my);
     const int x0 = mx * 8, y0 = my * 8;
     const bool interior = x0 + 8 <= g.W && y0 + 8 <= g.rowsAvail;
     u32 raw[8][6];
@@ -594,13 +610,17 @@ struct HistVisitor {
     __device__ __forceinline__ void eob() { atomicAdd(&acHist[0], 1u); }
 };
 
+// blockIdx.y is the image of the batch; a workgroup never mixes images, so its LDS counts
+// belong to one histogram set.
 __global__ __launch_bounds__(kEntThreads) void k_histogram(KGeom g, const int16_t* __restrict__ coef,
                                                            u64* __restrict__ hist) {
     __shared__ u32 lh[4 * 256];   // DC-Y, DC-C, AC-Y, AC-C (Encoder.cpp:368-416)
     for (int i = threadIdx.x; i < 1024; i += kEntThreads) lh[i] = 0;
     __syncthreads();
-    for (long long b = (long long)blockIdx.x * kEntThreads + threadIdx.x; b < g.totalBlocks;
-         b += (long long)gridDim.x * kEntThreads) {
+    const long long first = (long long)blockIdx.y * g.blocksPerImage;
+    for (long long bl = (long long)blockIdx.x * kEntThreads + threadIdx.x; bl < g.blocksPerImage;
+         bl += (long long)gridDim.x * kEntThreads) {
+        const long long b = first + bl;
         const long long m = b / g.bpm;
         const int k = (int)(b - m * g.bpm);
         const int c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
@@ -612,16 +632,18 @@ __global__ __launch_bounds__(kEntThreads) void k_histogram(KGeom g, const int16_
         walk_block(w, pred, vis);
     }
     __syncthreads();
+    u64* mine = hist + (long long)blockIdx.y * 1024;
     for (int i = threadIdx.x; i < 1024; i += kEntThreads)
-        if (lh[i] != 0) atomicAdd(&hist[i], (u64)lh[i]);
+        if (lh[i] != 0) atomicAdd(&mine[i], (u64)lh[i]);
 }
 
 hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(d_hist, 0, sizeof(u64) * 1024, s);
+    hipError_t e = hipMemsetAsync(d_hist, 0, sizeof(u64) * 1024 * g.batch, s);
     if (e != hipSuccess) return e;
-    long long grid = (g.totalBlocks + kEntThreads - 1) / kEntThreads;
-    if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(k_histogram, dim3((unsigned)grid), dim3(kEntThreads), 0, s, g, d_coef, d_hist);
+    long long grid = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
+    const long long cap = g.batch > 1 ? (4096 / g.batch > 8 ? 4096 / g.batch : 8) : 2048;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_histogram, dim3((unsigned)grid, (unsigned)g.batch), dim3(kEntThreads), 0, s, g, d_coef, d_hist);
     return hipGetLastError();
 }
 
@@ -647,16 +669,21 @@ __global__ __launch_bounds__(kEntThreads) void k_bit_lengths(KGeom g, const int1
                                                              u32* __restrict__ bitLen, u64* __restrict__ tileSums) {
     __shared__ u32 tab[4 * 256];
     __shared__ u32 partial[kEntThreads / 64];
-    for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = tables[i];
+    // blockIdx.y: image of the batch (always 0 for the tile-sum form), with its own tables.
+    const u32* myTables = tables + (long long)blockIdx.y * 1024;
+    for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = myTables[i];
     __syncthreads();
     constexpr int kSpan = kTileSums ? kLenTile : kEntThreads;   // blocks per workgroup pass
-    const long long spans = (g.totalBlocks + kSpan - 1) / kSpan;
+    const long long first = (long long)blockIdx.y * g.blocksPerImage;
+    const long long count = kTileSums ? g.totalBlocks : g.blocksPerImage;
+    const long long spans = (count + kSpan - 1) / kSpan;
     for (long long span = blockIdx.x; span < spans; span += gridDim.x) {
         u32 sum = 0;
 #pragma unroll 1
         for (int it = 0; it < kSpan / kEntThreads; ++it) {
-            const long long b = span * kSpan + it * kEntThreads + threadIdx.x;
-            if (b < g.totalBlocks) {
+            const long long bl = span * kSpan + it * kEntThreads + threadIdx.x;
+            const long long b = first + bl;
+            if (bl < count) {
                 const long long m = b / g.bpm;
                 const int k = (int)(b - m * g.bpm);
                 const int c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
@@ -839,7 +866,13 @@ static hipError_t exclusive_scan(const TIn* in, long long nHost, const u64* dN, 
 // image appends EOI.  Markers travel inside the stream so that the stuffing pass needs no
 // interval bookkeeping; it recognises them by position (is_marker_ff).
 __device__ __forceinline__ int interval_marker_bytes(const KGeom& g, long long k) {
-    return g.firstInterval + k > 0 ? 2 : 0;
+    return g.batch == 1 && g.firstInterval + k > 0 ? 2 : 0;
+}
+
+// Does EOI follow interval k?  The last interval of a band that ends its image; in a batch
+// every interval is a whole image.
+__device__ __forceinline__ bool interval_has_eoi(const KGeom& g, long long k) {
+    return g.writeEoi && (g.batch > 1 || k == g.intervals - 1);
 }
 
 __global__ void k_interval_bytes(KGeom g, const u64* __restrict__ bitOff, u64* __restrict__ ivBytes) {
@@ -849,7 +882,7 @@ __global__ void k_interval_bytes(KGeom g, const u64* __restrict__ bitOff, u64* _
     long long b1 = (k + 1) * g.mcusPerInterval * g.bpm;
     if (b1 > g.totalBlocks) b1 = g.totalBlocks;
     u64 n = ((bitOff[b1] - bitOff[b0] + 7) >> 3) + interval_marker_bytes(g, k);
-    if (k == g.intervals - 1 && g.writeEoi) n += 2;
+    if (interval_has_eoi(g, k)) n += 2;
     ivBytes[k] = n;
 }
 
@@ -868,7 +901,7 @@ __global__ __launch_bounds__(kScanThreads) void k_intervals_small(KGeom g, const
             long long b1 = b0 + perInterval;
             if (b1 > g.totalBlocks) b1 = g.totalBlocks;
             n = ((bitOff[b1] - bitOff[b0] + 7) >> 3) + interval_marker_bytes(g, k);
-            if (k == g.intervals - 1 && g.writeEoi) n += 2;
+            if (interval_has_eoi(g, k)) n += 2;
         }
         u64 total;
         const u64 ex = block_exclusive_scan(n, lds, total);
@@ -970,8 +1003,10 @@ __global__ __launch_bounds__(kEntThreads) void k_emit_bits(KGeom g, const int16_
     __shared__ u32 stage[kEmitStageWords];
     __shared__ u64 span[2];
     const long long blocksPerInterval = g.mcusPerInterval * g.bpm;
-    const long long b = (long long)blockIdx.x * kEntThreads + threadIdx.x;
-    const bool active = b < g.totalBlocks;
+    // blockIdx.y: image of the batch; a workgroup's blocks all belong to one image.
+    const long long bl = (long long)blockIdx.x * kEntThreads + threadIdx.x;
+    const long long b = (long long)blockIdx.y * g.blocksPerImage + bl;
+    const bool active = bl < g.blocksPerImage;
     long long m = 0;
     int k = 0, c = 0, padBits = 0, pred = 0;
     u32 leadMarker = 0;
@@ -1002,15 +1037,16 @@ __global__ __launch_bounds__(kEntThreads) void k_emit_bits(KGeom g, const int16_
         if (b == last - 1) {   // pad the interval to a byte boundary (BitBuffer.cpp:12-16)
             padBits = (int)((8 - (end & 7)) & 7);
             end += padBits;
-            if (b == g.totalBlocks - 1 && g.writeEoi) {
+            if (interval_has_eoi(g, iv)) {
                 tailEoi = true;
                 end += 16;
             }
         }
         if (threadIdx.x == 0) span[0] = pos;
-        if (threadIdx.x == kEntThreads - 1 || b == g.totalBlocks - 1) span[1] = end;
+        if (threadIdx.x == kEntThreads - 1 || bl == g.blocksPerImage - 1) span[1] = end;
     }
-    for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = tables[i];
+    const u32* myTables = tables + (long long)blockIdx.y * 1024;
+    for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = myTables[i];
     __syncthreads();
     const u64 wordBase = span[0] >> 5;
     const u64 nWords = ((span[1] + 31) >> 5) - wordBase;
@@ -1055,13 +1091,14 @@ __device__ __forceinline__ int count_ff(u32 w) {
 // bit writer placed in the stream?  Only reached for FF D0..D7 / FF D9 pairs, i.e. rarely.
 __device__ __forceinline__ bool is_marker_ff(const KGeom& g, const u64* __restrict__ ivOff, u64 bytes, u64 i,
                                              uint8_t next) {
-    if (next == 0xd9) return g.writeEoi && i + 2 == bytes;
-    if (next < 0xd0 || next > 0xd7) return false;
+    (void)bytes;
+    if (next != 0xd9 && (next < 0xd0 || next > 0xd7)) return false;
     long long lo = 0, hi = g.intervals - 1;   // last interval starting at or before i
     while (lo < hi) {
         const long long mid = (lo + hi + 1) >> 1;
         if (ivOff[mid] <= i) lo = mid; else hi = mid - 1;
     }
+    if (next == 0xd9) return interval_has_eoi(g, lo) && i + 2 == ivOff[lo + 1];
     return ivOff[lo] == i && interval_marker_bytes(g, lo) != 0;
 }
 
@@ -1108,13 +1145,32 @@ __global__ __launch_bounds__(256) void k_count_ff(KGeom g, const uint8_t* __rest
 
 // Copies the stream to the output with the stuffing bytes inserted.  A workgroup's 4 KiB
 // chunk becomes one contiguous output range, which is laid out in LDS at the output's own
-// 4-byte phase and stored as dwords.
+// 4-byte phase and stored as dwords.  In a batch the stream of image k goes behind header k
+// in slot k; a chunk that holds the end of one image and the start of the next is written
+// byte by byte instead.
 constexpr int kStuffStageBytes = 2 * kStuffChunk + 16;
 
+// Interval (= image of a batch) that contains stream byte i.
+__device__ __forceinline__ long long interval_of(const KGeom& g, const u64* __restrict__ ivOff, u64 i) {
+    long long lo = 0, hi = g.intervals - 1;
+    while (lo < hi) {
+        const long long mid = (lo + hi + 1) >> 1;
+        if (ivOff[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// Output position of stream byte i of image k, given the stuffing bytes in front of it.
+__device__ __forceinline__ long long batch_position(const BatchOutput& bo, const u64* __restrict__ ivOff, long long k,
+                                                    u64 i, u64 ffBefore) {
+    return k * bo.slotBytes + (long long)bo.hdrLen[k] + (long long)(i - ivOff[k]) + (long long)(ffBefore - bo.ffStart[k]);
+}
+
+template <bool kBatch>
 __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __restrict__ buf,
                                                      const u64* __restrict__ ivOff, const u64* __restrict__ ffOff,
                                                      u64* __restrict__ result, uint8_t* __restrict__ out,
-                                                     long long prefixLen, long long outCapacity) {
+                                                     long long prefixLen, long long outCapacity, BatchOutput bo) {
     __shared__ u64 lds[4];
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStuffStageBytes];
     const u64 bytes = result[2];
@@ -1129,61 +1185,126 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
             valid = (int)(bytes - (u64)i0 < 16 ? bytes - (u64)i0 : 16);
             mask = stuff_mask(g, buf, ivOff, bytes, i0, q);
         }
-        const long long base = prefixLen + c0 + (long long)ffOff[ch];
         u64 total;
         const u64 local = block_exclusive_scan((u64)(valid + __popc(mask)), lds, total);
-        if (base + (long long)total > outCapacity) {
-            if (threadIdx.x == 0) result[1] = 1;
+        // Output range of the chunk: one piece, except for a batch chunk that spans images.
+        long long base, limit;
+        bool onePiece = true;
+        if (kBatch) {
+            const long long k = interval_of(g, ivOff, (u64)c0);
+            const u64 cEnd = (u64)c0 + kStuffChunk < bytes ? (u64)c0 + kStuffChunk : bytes;
+            onePiece = cEnd <= ivOff[k + 1];
+            base = batch_position(bo, ivOff, k, (u64)c0, ffOff[ch]);
+            limit = (k + 1) * bo.slotBytes;
         } else {
-            const int phase = (int)((uintptr_t)(out + base) & 3);
-            if (valid > 0) {
-                uint8_t* dst = stage + phase + (int)local;
-                if (mask == 0 && valid == 16) {
-                    // Common case: plain copy; unaligned in LDS, so go by bytes.
+            base = prefixLen + c0 + (long long)ffOff[ch];
+            limit = outCapacity;
+        }
+        if (onePiece) {
+            if (base + (long long)total > limit) {
+                if (threadIdx.x == 0) result[1] = 1;
+            } else {
+                const int phase = (int)((uintptr_t)(out + base) & 3);
+                if (valid > 0) {
+                    uint8_t* dst = stage + phase + (int)local;
                     const u32 ws[4] = {q.x, q.y, q.z, q.w};
+                    if (mask == 0 && valid == 16) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) dst[j] = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
-                } else {
-                    const u32 ws[4] = {q.x, q.y, q.z, q.w};
-                    int o = 0;
-                    for (int j = 0; j < valid; ++j) {
-                        dst[o++] = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
-                        if ((mask >> j) & 1) dst[o++] = 0x00;
+                        for (int j = 0; j < 16; ++j) dst[j] = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
+                    } else {
+                        int o = 0;
+                        for (int j = 0; j < valid; ++j) {
+                            dst[o++] = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
+                            if ((mask >> j) & 1) dst[o++] = 0x00;
+                        }
+                    }
+                }
+                __syncthreads();
+                const int nTot = phase + (int)total;
+                uint8_t* dst = out + base - phase;   // 4-byte aligned
+                for (int d = threadIdx.x; d * 4 < nTot; d += 256) {
+                    const int lo4 = d * 4;
+                    if (lo4 >= phase && lo4 + 4 <= nTot) {
+                        *(u32*)(dst + lo4) = *(const u32*)(stage + lo4);
+                    } else {
+                        for (int bb = lo4 < phase ? phase : lo4; bb < lo4 + 4 && bb < nTot; ++bb) dst[bb] = stage[bb];
                     }
                 }
             }
-            __syncthreads();
-            const int nTot = phase + (int)total;
-            uint8_t* dst = out + base - phase;   // 4-byte aligned
-            for (int d = threadIdx.x; d * 4 < nTot; d += 256) {
-                const int lo4 = d * 4;
-                if (lo4 >= phase && lo4 + 4 <= nTot) {
-                    *(u32*)(dst + lo4) = *(const u32*)(stage + lo4);
+        } else if (valid > 0) {
+            // Batch chunk across an image boundary: every byte finds its own slot.
+            const u32 ws[4] = {q.x, q.y, q.z, q.w};
+            long long k = interval_of(g, ivOff, (u64)i0);
+            u64 ff = ffOff[ch] + (local - (u64)((long long)i0 - c0));   // stuffing bytes in front of byte i0
+            bool overflow = false;
+            for (int j = 0; j < valid; ++j) {
+                const u64 i = (u64)(i0 + j);
+                while (i >= ivOff[k + 1]) ++k;
+                const long long pos = batch_position(bo, ivOff, k, i, ff);
+                const int extra = (mask >> j) & 1;
+                if (pos + 1 + extra <= (k + 1) * bo.slotBytes) {
+                    out[pos] = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
+                    if (extra) out[pos + 1] = 0x00;
                 } else {
-                    for (int bb = lo4 < phase ? phase : lo4; bb < lo4 + 4 && bb < nTot; ++bb) dst[bb] = stage[bb];
+                    overflow = true;
                 }
+                ff += extra;
             }
+            if (overflow) result[1] = 1;
         }
-        if (ch == chunks - 1 && threadIdx.x == 0) result[0] = (u64)(base + (long long)total);
+        if (!kBatch && ch == chunks - 1 && threadIdx.x == 0) result[0] = (u64)(base + (long long)total);
         __syncthreads();
     }
 }
 
-hipError_t launch_entropy(const KGeom& g, const int16_t* d_coef, const u32* d_tables, const EntropyWorkspace& ws,
-                          uint8_t* d_out, long long prefixLen, long long outCapacity, int writeEoi, hipStream_t s) {
-    (void)writeEoi;   // carried in g.writeEoi
+// Batch: stuffing bytes in front of each image's stream (and, for k = batch, in total).
+__global__ __launch_bounds__(256) void k_image_ff_start(KGeom g, const uint8_t* __restrict__ buf,
+                                                        const u64* __restrict__ ivOff, const u64* __restrict__ ffOff,
+                                                        const u64* __restrict__ result, u64* __restrict__ ffStart) {
+    __shared__ u64 lds[4];
+    const u64 bytes = result[2];
+    const long long k = blockIdx.x;
+    const u64 pos = ivOff[k];
+    const long long ch = (long long)(pos / kStuffChunk);
+    const long long i0 = ch * kStuffChunk + (long long)threadIdx.x * 16;
+    int cnt = 0;
+    if ((u64)i0 < pos) {
+        uint4 q;
+        u32 mask = stuff_mask(g, buf, ivOff, bytes, i0, q);
+        const u64 span = pos - (u64)i0;
+        if (span < 16) mask &= (1u << span) - 1u;
+        cnt = __popc(mask);
+    }
+    u64 total;
+    block_exclusive_scan((u64)cnt, lds, total);
+    if (threadIdx.x == 0) ffStart[k] = ffOff[ch] + total;
+}
+
+// Batch: header k to the front of slot k.
+__global__ __launch_bounds__(256) void k_copy_headers(BatchOutput bo) {
+    const long long k = blockIdx.x;
+    const uint8_t* src = bo.hdr + k * bo.hdrPitch;
+    uint8_t* dst = bo.out + k * bo.slotBytes;
+    const u32 n = bo.hdrLen[k];
+    for (u32 i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+
+static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const u32* d_tables,
+                                    const EntropyWorkspace& ws, uint8_t* d_out, long long prefixLen,
+                                    long long outCapacity, const BatchOutput* bo, hipStream_t s) {
     const long long tiles = (g.totalBlocks + kLenTile - 1) / kLenTile;
-    const bool fusedSums = tiles >= 1024;   // enough tiles to fill the chip with whole-tile workgroups
+    const bool fusedSums = g.batch == 1 && tiles >= 1024;   // enough tiles to fill the chip with whole-tile workgroups
     hipError_t e;
     if (fusedSums) {
         const unsigned lenGrid = (unsigned)(tiles > 2048 ? 2048 : tiles);
         hipLaunchKernelGGL(k_bit_lengths<true>, dim3(lenGrid), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.bitLen,
                            ws.scanTmp);
     } else {
-        long long lenGrid = (g.totalBlocks + kEntThreads - 1) / kEntThreads;
-        if (lenGrid > 4096) lenGrid = 4096;
-        hipLaunchKernelGGL(k_bit_lengths<false>, dim3((unsigned)lenGrid), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
-                           ws.bitLen, ws.scanTmp);
+        long long lenGrid = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
+        const long long cap = g.batch > 1 ? (8192 / g.batch > 8 ? 8192 / g.batch : 8) : 4096;
+        if (lenGrid > cap) lenGrid = cap;
+        hipLaunchKernelGGL(k_bit_lengths<false>, dim3((unsigned)lenGrid, (unsigned)g.batch), dim3(kEntThreads), 0, s, g,
+                           d_coef, d_tables, ws.bitLen, ws.scanTmp);
     }
     e = exclusive_scan<u32>(ws.bitLen, g.totalBlocks, nullptr, g.totalBlocks, ws.scanTmp, ws.bitOff, s, fusedSums);
     if (e != hipSuccess) return e;
@@ -1200,18 +1321,38 @@ hipError_t launch_entropy(const KGeom& g, const int16_t* d_coef, const u32* d_ta
     zeroGrid = zeroGrid < 1 ? 1 : (zeroGrid > 1024 ? 1024 : zeroGrid);
     hipLaunchKernelGGL(k_prepare_unstuffed, dim3((unsigned)zeroGrid), dim3(256), 0, s, ws.result, (uint4*)ws.unstuffed,
                        ws.unstuffedCap);
-    const long long emitGrid = (g.totalBlocks + kEntThreads - 1) / kEntThreads;
-    hipLaunchKernelGGL(k_emit_bits, dim3((unsigned)emitGrid), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.bitOff,
-                       ws.ivOff, (u32*)ws.unstuffed);
+    const long long emitGrid = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
+    hipLaunchKernelGGL(k_emit_bits, dim3((unsigned)emitGrid, (unsigned)g.batch), dim3(kEntThreads), 0, s, g, d_coef,
+                       d_tables, ws.bitOff, ws.ivOff, (u32*)ws.unstuffed);
     long long chunkGrid = ws.maxChunks < 2048 ? ws.maxChunks : 2048;
     if (chunkGrid < 1) chunkGrid = 1;
     hipLaunchKernelGGL(k_count_ff, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.result,
                        ws.ffCount);
     e = exclusive_scan<u32>(ws.ffCount, 0, ws.result + 3, ws.maxChunks, ws.scanTmp, ws.ffOff, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_stuff_bytes, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.ffOff,
-                       ws.result, d_out, prefixLen, outCapacity);
+    if (bo) {
+        hipLaunchKernelGGL(k_image_ff_start, dim3((unsigned)(g.batch + 1)), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
+                           ws.ffOff, ws.result, bo->ffStart);
+        hipLaunchKernelGGL(k_copy_headers, dim3((unsigned)g.batch), dim3(256), 0, s, *bo);
+        hipLaunchKernelGGL(k_stuff_bytes<true>, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
+                           ws.ffOff, ws.result, bo->out, 0, 0, *bo);
+    } else {
+        BatchOutput none = {};
+        hipLaunchKernelGGL(k_stuff_bytes<false>, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
+                           ws.ffOff, ws.result, d_out, prefixLen, outCapacity, none);
+    }
     return hipGetLastError();
+}
+
+hipError_t launch_entropy(const KGeom& g, const int16_t* d_coef, const u32* d_tables, const EntropyWorkspace& ws,
+                          uint8_t* d_out, long long prefixLen, long long outCapacity, int writeEoi, hipStream_t s) {
+    (void)writeEoi;   // carried in g.writeEoi
+    return run_entropy_stage(g, d_coef, d_tables, ws, d_out, prefixLen, outCapacity, nullptr, s);
+}
+
+hipError_t launch_entropy_batch(const KGeom& g, const int16_t* d_coef, const u32* d_tables,
+                                const EntropyWorkspace& ws, const BatchOutput& bo, hipStream_t s) {
+    return run_entropy_stage(g, d_coef, d_tables, ws, nullptr, 0, 0, &bo, s);
 }
 
 }  // namespace jpeghip
