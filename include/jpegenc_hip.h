@@ -121,6 +121,18 @@ int jpeg_hip_encode(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int
 int jpeg_hip_encode_host(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format, int64_t stride_bytes,
                          const jpeg_hip_params* params, uint8_t* h_out, int64_t out_capacity, int64_t* out_len);
 
+/* The same for `count` equally shaped images in one call: the driver's loop over files
+ * (JPEG-Encoder-SIMD.cpp:397-441 once per image) for frames that share size, sampling scheme
+ * and quantization tables.  Image k starts at d_rgb + k * image_stride_bytes; its file --
+ * byte-identical to what jpeg_hip_encode produces for that image, with its own optimized
+ * Huffman tables -- is written to d_out + k * slot_bytes and is h_lens[k] bytes long.
+ * params->restart_interval and the band rows must be 0.  Every kernel runs once over the
+ * whole batch (large batches are cut into passes of about 1.5 GiB of coefficients).
+ * JPEG_HIP_ERR_BUFFER_TOO_SMALL if a file does not fit its slot. */
+int jpeg_hip_encode_batch(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
+                          int64_t image_stride_bytes, int count, const jpeg_hip_params* params, uint8_t* d_out,
+                          int64_t slot_bytes, int64_t* h_lens);
+
 /* ---- staged entry points (what the host Encoder class drives) --------------------------- */
 
 /* Image(w, h, scheme) + Encoder(image, qtables): fixes geometry and tables, sizes the

@@ -7,6 +7,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "internal.h"
 #include "kernels.h"
@@ -107,6 +109,29 @@ struct DevBuf {
     }
 };
 
+// Growable pinned host block.
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        release();
+        const size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 struct Pinned {
     float qtab[3 * 192];   // divisors, then the high and low parts of their reciprocals
     uint64_t hist[4 * 256];
@@ -130,7 +155,8 @@ struct jpeg_hip_ctx {
     int fmt = JPEG_HIP_RGB8;
     int64_t stride = 0;
     DevBuf pixels, coef, qtab, hist, tables, bitLen, bitOff, ivBytes, ivOff, ffCount, ffOff, scanTmp, result, unstuffed,
-        staging;
+        staging, batchHdr, batchHdrLen, batchFfStart;
+    HostBuf hostHist, hostTables, hostHdr, hostHdrLen, hostOffsets;
     EntropyWorkspace ws;
     Pinned* pin = nullptr;
     uint8_t lengths[4][256];
@@ -205,22 +231,25 @@ void fill_kgeom(jpeg_hip_ctx* ctx) {
     k.imageStrideBytes = 0;
 }
 
-int ensure_workspace(jpeg_hip_ctx* ctx) {
+// Workspace for `images` images of the current geometry (1 outside batch mode; in a batch
+// every image is one interval of the combined stream).
+int ensure_workspace(jpeg_hip_ctx* ctx, int images = 1) {
     const Geometry& g = ctx->geo;
-    const int64_t nb = g.totalBlocks;
+    const int64_t nb = g.totalBlocks * images;
+    const int64_t intervals = images > 1 ? images : g.intervals;
     // Entropy-coded bits plus the RSTn/EOI markers the bit writer places in the stream.
-    const int64_t unstuffedCap = (worst_case_scan_bytes(nb) + 2 * g.intervals + 2 + kStuffChunk + 63) / 16 * 16;
+    const int64_t unstuffedCap = (worst_case_scan_bytes(nb) + 2 * intervals + 2 + kStuffChunk + 63) / 16 * 16;
     const int64_t maxChunks = (unstuffedCap + kStuffChunk - 1) / kStuffChunk;
     int64_t scanItems = nb > maxChunks ? nb : maxChunks;
-    if (g.intervals > scanItems) scanItems = g.intervals;
+    if (intervals > scanItems) scanItems = intervals;
     HIP_TRY(ctx, ctx->coef.ensure((size_t)nb * 128));
     HIP_TRY(ctx, ctx->qtab.ensure(sizeof ctx->pin->qtab));
-    HIP_TRY(ctx, ctx->hist.ensure(1024 * sizeof(uint64_t)));
-    HIP_TRY(ctx, ctx->tables.ensure(1024 * sizeof(uint32_t)));
+    HIP_TRY(ctx, ctx->hist.ensure(1024 * sizeof(uint64_t) * images));
+    HIP_TRY(ctx, ctx->tables.ensure(1024 * sizeof(uint32_t) * images));
     HIP_TRY(ctx, ctx->bitLen.ensure((size_t)nb * 4));
     HIP_TRY(ctx, ctx->bitOff.ensure((size_t)(nb + 1) * 8));
-    HIP_TRY(ctx, ctx->ivBytes.ensure((size_t)g.intervals * 8));
-    HIP_TRY(ctx, ctx->ivOff.ensure((size_t)(g.intervals + 1) * 8));
+    HIP_TRY(ctx, ctx->ivBytes.ensure((size_t)intervals * 8));
+    HIP_TRY(ctx, ctx->ivOff.ensure((size_t)(intervals + 1) * 8));
     HIP_TRY(ctx, ctx->ffCount.ensure((size_t)maxChunks * 4));
     HIP_TRY(ctx, ctx->ffOff.ensure((size_t)(maxChunks + 1) * 8));
     HIP_TRY(ctx, ctx->scanTmp.ensure((size_t)(scanItems / 2048 + 2) * 8));
@@ -378,8 +407,10 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->bitLen, &ctx->bitOff,
                       &ctx->ivBytes, &ctx->ivOff, &ctx->ffCount, &ctx->ffOff, &ctx->scanTmp, &ctx->result,
-                      &ctx->unstuffed, &ctx->staging};
+                      &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart};
     for (DevBuf* b : bufs) b->release();
+    HostBuf* hbufs[] = {&ctx->hostHist, &ctx->hostTables, &ctx->hostHdr, &ctx->hostHdrLen, &ctx->hostOffsets};
+    for (HostBuf* b : hbufs) b->release();
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
@@ -665,3 +696,160 @@ int jpeg_hip_get_timings(jpeg_hip_ctx* ctx, float out_ms[4]) {
 }
 
 }  // extern "C"
+
+// ---- batch of equally shaped images ------------------------------------------------------
+namespace {
+
+constexpr int kBatchHeaderPitch = 1024;          // bytes reserved per header in the staging blocks
+constexpr int64_t kBatchMaxBlocks = 12 << 20;    // blocks per pass: 1.5 GiB of coefficients
+
+// Huffman tables and headers of images [k0, k1) of a pass, from their histograms.
+void batch_tables_worker(const jpeg_hip_ctx* ctx, int k0, int k1, const uint64_t* hist, uint32_t* tables, uint8_t* hdr,
+                         uint32_t* hdrLen, int* status) {
+    uint8_t lengths[4][256];
+    uint16_t codes[4][256];
+    for (int k = k0; k < k1; ++k) {
+        const uint64_t* h = hist + (size_t)k * 1024;
+        for (int t = 0; t < 4; ++t) {
+            uint64_t total = 0;
+            for (int s = 0; s < 256; ++s) total += h[t * 256 + s];
+            if (total == 0) {
+                *status = JPEG_HIP_ERR_INVALID_ARGUMENT;
+                return;
+            }
+            huffman_from_histogram(h + t * 256, lengths[t], codes[t]);
+            for (int s = 0; s < 256; ++s) tables[(size_t)k * 1024 + t * 256 + s] = ((uint32_t)lengths[t][s] << 16) | codes[t][s];
+        }
+        const int n = write_headers(ctx->prm, ctx->geo, lengths, codes, hdr + (size_t)k * kBatchHeaderPitch, kBatchHeaderPitch);
+        if (n < 0) {
+            *status = n;
+            return;
+        }
+        hdrLen[k] = (uint32_t)n;
+    }
+}
+
+// One pass: `n` images starting at d_rgb, output slots starting at d_out.
+int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStride, int n, uint8_t* d_out,
+                      int64_t slotBytes, int64_t* lens) {
+    const Geometry& g = ctx->geo;
+    fill_kgeom(ctx);
+    KGeom& k = ctx->kg;
+    k.batch = n;
+    k.nMcu = g.nMcu * n;
+    k.totalBlocks = g.totalBlocks * n;
+    k.imageStrideBytes = imageStride;
+    k.mcusPerInterval = g.nMcu;
+    k.intervals = n;
+    k.firstInterval = 0;
+    k.writeEoi = 1;
+    mark(ctx, 0);
+    HIP_TRY(ctx, launch_transform(k, d_rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, ctx->stream));
+    mark(ctx, 1);
+    HIP_TRY(ctx, launch_histogram(k, (const int16_t*)ctx->coef.p, (unsigned long long*)ctx->hist.p, ctx->stream));
+    mark(ctx, 2);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->hostHist.p, ctx->hist.p, (size_t)n * 1024 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+    auto t0 = std::chrono::steady_clock::now();
+    unsigned hw = std::thread::hardware_concurrency();
+    int workers = (int)(hw == 0 ? 1 : (hw > 16 ? 16 : hw));
+    if (workers > (n + 3) / 4) workers = (n + 3) / 4;
+    std::vector<int> status((size_t)workers, JPEG_HIP_OK);
+    std::vector<std::thread> pool;
+    const int per = (n + workers - 1) / workers;
+    for (int w = 1; w < workers; ++w) {
+        const int a = w * per, b = a + per < n ? a + per : n;
+        if (a >= b) break;
+        pool.emplace_back(batch_tables_worker, ctx, a, b, (const uint64_t*)ctx->hostHist.p, (uint32_t*)ctx->hostTables.p,
+                          (uint8_t*)ctx->hostHdr.p, (uint32_t*)ctx->hostHdrLen.p, &status[(size_t)w]);
+    }
+    batch_tables_worker(ctx, 0, per < n ? per : n, (const uint64_t*)ctx->hostHist.p, (uint32_t*)ctx->hostTables.p,
+                        (uint8_t*)ctx->hostHdr.p, (uint32_t*)ctx->hostHdrLen.p, &status[0]);
+    for (auto& t : pool) t.join();
+    for (int st : status)
+        if (st != JPEG_HIP_OK) return fail(ctx, st, "Huffman tables or headers of a batch image could not be built");
+    ctx->times[3] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->hostTables.p, (size_t)n * 1024 * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->batchHdr.p, ctx->hostHdr.p, (size_t)n * kBatchHeaderPitch, hipMemcpyHostToDevice,
+                                ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->batchHdrLen.p, ctx->hostHdrLen.p, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    BatchOutput bo;
+    bo.out = d_out;
+    bo.slotBytes = slotBytes;
+    bo.hdr = (const uint8_t*)ctx->batchHdr.p;
+    bo.hdrLen = (const uint32_t*)ctx->batchHdrLen.p;
+    bo.hdrPitch = kBatchHeaderPitch;
+    bo.ffStart = (unsigned long long*)ctx->batchFfStart.p;
+    mark(ctx, 3);
+    HIP_TRY(ctx, launch_entropy_batch(k, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, bo, ctx->stream));
+    mark(ctx, 4);
+    uint64_t* off = (uint64_t*)ctx->hostOffsets.p;   // [n+1] stream offsets, [n+1] stuffing offsets, [4] result
+    HIP_TRY(ctx, hipMemcpyAsync(off, ctx->ivOff.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(off + n + 1, ctx->batchFfStart.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(off + 2 * (n + 1), ctx->result.p, 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->times[0] += ms;
+        if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->times[1] += ms;
+        if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->times[2] += ms;
+    }
+    bool overflow = off[2 * (n + 1) + 1] != 0;
+    const uint32_t* hdrLen = (const uint32_t*)ctx->hostHdrLen.p;
+    for (int i = 0; i < n; ++i) {
+        lens[i] = (int64_t)hdrLen[i] + (int64_t)(off[i + 1] - off[i]) + (int64_t)(off[n + 1 + i + 1] - off[n + 1 + i]);
+        if (lens[i] > slotBytes) overflow = true;
+    }
+    if (overflow) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "an output slot is too small for its image");
+    return JPEG_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" int jpeg_hip_encode_batch(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
+                                     int64_t image_stride_bytes, int count, const jpeg_hip_params* params, uint8_t* d_out,
+                                     int64_t slot_bytes, int64_t* h_lens) {
+    if (!ctx || !params || !d_out || !h_lens) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (count < 1) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "batch count must be at least 1");
+    if (params->restart_interval != 0 || params->mcu_row_begin != 0 || params->mcu_row_end != 0)
+        return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "batch images are whole images without restart intervals");
+    if (slot_bytes < kBatchHeaderPitch) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "output slots are smaller than the headers");
+    int st = jpeg_hip_begin(ctx, params);
+    if (st != JPEG_HIP_OK) return st;
+    st = jpeg_hip_bind_pixels(ctx, d_rgb, sample_format, stride_bytes);
+    if (st != JPEG_HIP_OK) return st;
+    const Geometry& g = ctx->geo;
+    const int64_t minImage = stride_bytes * (int64_t)(g.height - 1) + (int64_t)g.width * 3 * bytes_per_sample(sample_format);
+    if (count > 1 && image_stride_bytes < minImage)
+        return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "image stride is smaller than one image");
+    if (sample_format == JPEG_HIP_RGBF32 && image_stride_bytes % 4 != 0)
+        return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "float pixels must be 4-byte aligned");
+    int64_t perPass = kBatchMaxBlocks / g.totalBlocks;
+    if (perPass < 1) perPass = 1;
+    if (perPass > count) perPass = count;
+    const int pass = (int)perPass;
+    st = ensure_workspace(ctx, pass);
+    if (st != JPEG_HIP_OK) return st;
+    HIP_TRY(ctx, ctx->batchHdr.ensure((size_t)pass * kBatchHeaderPitch));
+    HIP_TRY(ctx, ctx->batchHdrLen.ensure((size_t)pass * 4));
+    HIP_TRY(ctx, ctx->batchFfStart.ensure((size_t)(pass + 1) * 8));
+    HIP_TRY(ctx, ctx->hostHist.ensure((size_t)pass * 1024 * 8));
+    HIP_TRY(ctx, ctx->hostTables.ensure((size_t)pass * 1024 * 4));
+    HIP_TRY(ctx, ctx->hostHdr.ensure((size_t)pass * kBatchHeaderPitch));
+    HIP_TRY(ctx, ctx->hostHdrLen.ensure((size_t)pass * 4));
+    HIP_TRY(ctx, ctx->hostOffsets.ensure((size_t)(2 * (pass + 1) + 4) * 8));
+    ctx->times[0] = ctx->times[1] = ctx->times[2] = ctx->times[3] = 0;
+    for (int first = 0; first < count; first += pass) {
+        const int n = count - first < pass ? count - first : pass;
+        st = encode_batch_pass(ctx, (const uint8_t*)d_rgb + (int64_t)first * image_stride_bytes, image_stride_bytes, n,
+                               d_out + (int64_t)first * slot_bytes, slot_bytes, h_lens + first);
+        if (st != JPEG_HIP_OK) return st;
+    }
+    // The context no longer describes a single image.
+    ctx->transformed = false;
+    ctx->hasTables = false;
+    ctx->stagedScanLen = -1;
+    return JPEG_HIP_OK;
+}

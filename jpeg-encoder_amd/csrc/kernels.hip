@@ -511,7 +511,8 @@ static bool scheme_is(const KGeom& g, int wf, int hf, int method) {
 
 hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef, hipStream_t s) {
     const bool bytesAligned = g.sampleFormat == JPEG_HIP_RGB8 && g.stages == JPEG_HIP_STAGE_ALL &&
-                              (g.strideBytes & 3) == 0 && ((uintptr_t)d_rgb & 3) == 0;
+                              (g.strideBytes & 3) == 0 && ((uintptr_t)d_rgb & 3) == 0 &&
+                              (g.batch == 1 || (g.imageStrideBytes & 3) == 0);
     if (bytesAligned && scheme_is(g, 2, 2, JPEG_HIP_AVERAGE)) {
         const long long grid = (g.nMcu + k420Mcus - 1) / k420Mcus;
         hipLaunchKernelGGL(k_transform_420, dim3((unsigned)grid), dim3(256), 0, s, g, (const unsigned char*)d_rgb, d_qtab,

@@ -12,13 +12,14 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.abspath(os.path.join(_PKG, "..", "..", "lib", "libjpegenc_hip.so"))
 
 OK = 0
+ERR_INVALID_ARGUMENT, ERR_HIP, ERR_BUFFER_TOO_SMALL, ERR_BAD_STATE, ERR_NO_DEVICE = -1, -2, -3, -4, -5
 RGB8, RGBF32 = 0, 1
 STAGE_YCBCR, STAGE_SUBSAMPLE, STAGE_ALL = 1, 2, 3
 DC, AC = 0, 1
 
 EXPORTS = [
     "jpeg_hip_create", "jpeg_hip_destroy", "jpeg_hip_last_error", "jpeg_hip_status_string", "jpeg_hip_stream",
-    "jpeg_hip_compute_layout", "jpeg_hip_encode", "jpeg_hip_encode_host", "jpeg_hip_begin", "jpeg_hip_upload_pixels",
+    "jpeg_hip_compute_layout", "jpeg_hip_encode", "jpeg_hip_encode_host", "jpeg_hip_encode_batch", "jpeg_hip_begin", "jpeg_hip_upload_pixels",
     "jpeg_hip_bind_pixels", "jpeg_hip_transform", "jpeg_hip_histograms", "jpeg_hip_histograms_host",
     "jpeg_hip_huffman_from_histogram", "jpeg_hip_write_dht", "jpeg_hip_write_headers", "jpeg_hip_set_huffman",
     "jpeg_hip_build_huffman", "jpeg_hip_get_huffman", "jpeg_hip_emit_scan", "jpeg_hip_emit_scan_host",
@@ -77,6 +78,7 @@ def lib():
         L.jpeg_hip_compute_layout.argtypes = [C.POINTER(Params), C.POINTER(Layout)]
         L.jpeg_hip_encode.argtypes = [vp, vp, i32, i64, C.POINTER(Params), vp, i64, C.POINTER(i64)]
         L.jpeg_hip_encode_host.argtypes = [vp, vp, i32, i64, C.POINTER(Params), vp, i64, C.POINTER(i64)]
+        L.jpeg_hip_encode_batch.argtypes = [vp, vp, i32, i64, i64, i32, C.POINTER(Params), vp, i64, vp]
         L.jpeg_hip_begin.argtypes = [vp, C.POINTER(Params)]
         L.jpeg_hip_upload_pixels.argtypes = [vp, vp, i32, i64]
         L.jpeg_hip_bind_pixels.argtypes = [vp, vp, i32, i64]
@@ -201,6 +203,13 @@ class Context:
         self._check(lib().jpeg_hip_encode(self._h, C.c_void_p(d_rgb), fmt, stride, C.byref(params), C.c_void_p(d_out),
                                           capacity, C.byref(n)))
         return n.value
+
+    def encode_batch(self, d_rgb, fmt, stride, image_stride, count, params, d_out, slot_bytes):
+        """`count` images of one shape, all resident in HBM -> int64 array of file lengths."""
+        lens = np.zeros(count, np.int64)
+        self._check(lib().jpeg_hip_encode_batch(self._h, C.c_void_p(d_rgb), fmt, stride, image_stride, count,
+                                                C.byref(params), C.c_void_p(d_out), slot_bytes, _np(lens)))
+        return lens
 
     def encode_host(self, rgb, params, stride=None):
         """rgb: numpy uint8/float32 [H, W, 3] on the host -> JFIF bytes."""

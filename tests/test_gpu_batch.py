@@ -1,0 +1,93 @@
+"""Batch entry point vs the CPU oracle, image by image (needs an MI355X)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from jpegenc_amd import binding as B, synth, tables as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = B.Context(0)
+    yield c
+    c.close()
+
+
+def _run_batch(ctx, imgs, scheme, qt, slot=None, image_pad=0, row_pad=0, pad_ones=False):
+    import torch
+    n, h, w = len(imgs), imgs[0].shape[0], imgs[0].shape[1]
+    stride = w * 3 + row_pad
+    image_stride = stride * h + image_pad
+    host = np.zeros(n * image_stride, np.uint8)
+    for k, im in enumerate(imgs):
+        view = host[k * image_stride:k * image_stride + stride * h].reshape(h, stride)
+        view[:, :w * 3] = im.reshape(h, w * 3)
+    d_rgb = torch.from_numpy(host).cuda()
+    prm = B.make_params(w, h, scheme, qt, pad_ones=pad_ones)
+    if slot is None:
+        slot = int(B.compute_layout(prm).max_jpeg_bytes)
+    d_out = torch.full((n * slot,), 0xAA, dtype=torch.uint8, device="cuda")
+    lens = ctx.encode_batch(d_rgb.data_ptr(), B.RGB8, stride, image_stride, n, prm, d_out.data_ptr(), slot)
+    out = d_out.cpu().numpy()
+    return [out[k * slot:k * slot + int(lens[k])].tobytes() for k in range(n)], out, lens, slot
+
+
+@pytest.mark.parametrize("scheme", ["420", "444", "422", "411"])
+def test_batch_matches_oracle_per_image(ctx, scheme):
+    # different content per image -> different Huffman tables and stream lengths per slot
+    for (w, h, n) in [(64, 48, 5), (37, 29, 9), (250, 130, 3), (16, 16, 33), (8, 8, 70)]:
+        imgs = [synth.generate("noise" if k % 3 == 0 else "natural", w, h, seed=17 * k + w) for k in range(n)]
+        if n > 2:
+            imgs[1] = np.zeros_like(imgs[1])            # flat image: shortest possible stream
+            imgs[2] = np.full_like(imgs[2], 255)
+        qt = T.quality_tables(90)
+        files, out, lens, slot = _run_batch(ctx, imgs, T.SCHEMES[scheme], qt)
+        for k, im in enumerate(imgs):
+            assert files[k] == O.encode(im, T.SCHEMES[scheme], qt).jpeg, (scheme, w, h, k)
+            # nothing written behind the file inside its slot
+            assert np.all(out[k * slot + int(lens[k]):(k + 1) * slot] == 0xAA), (scheme, w, h, k)
+
+
+def test_batch_strides_unaligned_and_pad_ones(ctx):
+    imgs = [synth.generate("noise", 123, 77, seed=k) for k in range(6)]
+    qt = T.NAMED_TABLES["ones"]
+    for row_pad, image_pad in [(0, 0), (3, 0), (1, 5), (4, 64)]:
+        files, _, _, _ = _run_batch(ctx, imgs, T.SCHEME_420, qt, image_pad=image_pad, row_pad=row_pad, pad_ones=True)
+        for k, im in enumerate(imgs):
+            assert files[k] == O.encode(im, T.SCHEME_420, qt, pad_ones=True).jpeg, (row_pad, image_pad, k)
+
+
+def test_batch_equals_single_encodes_1080p(ctx):
+    import torch
+    w, h, n = 1920, 1080, 6
+    imgs = [synth.generate("natural", w, h, seed=k) for k in range(n)]
+    qt = T.quality_tables(90)
+    files, _, _, _ = _run_batch(ctx, imgs, T.SCHEME_420, qt, slot=2 << 20)
+    prm = B.make_params(w, h, T.SCHEME_420, qt)
+    assert files[0] == O.encode(imgs[0], T.SCHEME_420, qt).jpeg
+    for k in range(1, n):
+        assert files[k] == ctx.encode_host(imgs[k], prm), k
+
+
+def test_batch_of_one_and_errors(ctx):
+    import torch
+    img = synth.generate("natural", 100, 60)
+    qt = T.STANDARD_TABLES
+    files, _, _, _ = _run_batch(ctx, [img], T.SCHEME_444, qt)
+    assert files[0] == O.encode(img, T.SCHEME_444, qt).jpeg
+    # slot too small for the file
+    with pytest.raises(B.JpegHipError) as e:
+        _run_batch(ctx, [synth.generate("noise", 100, 60, seed=k) for k in range(3)], T.SCHEME_444,
+                   T.NAMED_TABLES["ones"], slot=4096)
+    assert e.value.status == B.ERR_BUFFER_TOO_SMALL
+    # restart intervals are not part of batch mode
+    prm = B.make_params(100, 60, T.SCHEME_444, qt, restart_interval=4)
+    buf = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    with pytest.raises(B.JpegHipError) as e:
+        ctx.encode_batch(buf.data_ptr(), B.RGB8, 300, 18000, 2, prm, buf.data_ptr(), 1 << 18)
+    assert e.value.status == B.ERR_INVALID_ARGUMENT
+    # the context still works for single images afterwards
+    prm = B.make_params(100, 60, T.SCHEME_444, qt)
+    assert ctx.encode_host(img, prm) == O.encode(img, T.SCHEME_444, qt).jpeg
