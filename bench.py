@@ -132,7 +132,7 @@ def main():
         image_stride = stride * height
         rgb = torch.empty(batch * image_stride, dtype=torch.uint8, device=dev)
         for k in range(batch):
-            frame = synth_torch.generate(kind, width, height, seed=1000 * rank + k, device=dev)
+            frame = synth_torch.generate(kind, width, height, seed=1000 + rank * batch + k, device=dev)
             rgb[k * image_stride:(k + 1) * image_stride] = frame.reshape(-1)
         del frame
     else:

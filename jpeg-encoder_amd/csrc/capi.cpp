@@ -151,11 +151,12 @@ struct jpeg_hip_ctx {
     KGeom kg;
     bool begun = false, hasPixels = false, transformed = false, hasTables = false;
     int64_t stagedScanLen = -1;   // scan of the current coefficients and tables held in `staging`, or -1
+    int64_t streamBits = -1;      // entropy-coded bits the installed tables spend on the histograms they came from, or -1
     const void* rgb = nullptr;
     int fmt = JPEG_HIP_RGB8;
     int64_t stride = 0;
-    DevBuf pixels, coef, qtab, hist, tables, bitLen, bitOff, ivBytes, ivOff, ffCount, ffOff, scanTmp, result, unstuffed,
-        staging, batchHdr, batchHdrLen, batchFfStart;
+    DevBuf pixels, coef, qtab, hist, tables, ivOff, ffCount, ffOff, scanTmp, result, unstuffed,
+        staging, batchHdr, batchHdrLen, batchFfStart, tileState;
     HostBuf hostHist, hostTables, hostHdr, hostHdrLen, hostOffsets;
     EntropyWorkspace ws;
     Pinned* pin = nullptr;
@@ -240,25 +241,20 @@ int ensure_workspace(jpeg_hip_ctx* ctx, int images = 1) {
     // Entropy-coded bits plus the RSTn/EOI markers the bit writer places in the stream.
     const int64_t unstuffedCap = (worst_case_scan_bytes(nb) + 2 * intervals + 2 + kStuffChunk + 63) / 16 * 16;
     const int64_t maxChunks = (unstuffedCap + kStuffChunk - 1) / kStuffChunk;
-    int64_t scanItems = nb > maxChunks ? nb : maxChunks;
-    if (intervals > scanItems) scanItems = intervals;
+    const int64_t scanItems = maxChunks;
     HIP_TRY(ctx, ctx->coef.ensure((size_t)nb * 128));
     HIP_TRY(ctx, ctx->qtab.ensure(sizeof ctx->pin->qtab));
     HIP_TRY(ctx, ctx->hist.ensure(1024 * sizeof(uint64_t) * images));
     HIP_TRY(ctx, ctx->tables.ensure(1024 * sizeof(uint32_t) * images));
-    HIP_TRY(ctx, ctx->bitLen.ensure((size_t)nb * 4));
-    HIP_TRY(ctx, ctx->bitOff.ensure((size_t)(nb + 1) * 8));
-    HIP_TRY(ctx, ctx->ivBytes.ensure((size_t)intervals * 8));
     HIP_TRY(ctx, ctx->ivOff.ensure((size_t)(intervals + 1) * 8));
     HIP_TRY(ctx, ctx->ffCount.ensure((size_t)maxChunks * 4));
     HIP_TRY(ctx, ctx->ffOff.ensure((size_t)(maxChunks + 1) * 8));
     HIP_TRY(ctx, ctx->scanTmp.ensure((size_t)(scanItems / 2048 + 2) * 8));
     HIP_TRY(ctx, ctx->result.ensure(4 * 8));
     HIP_TRY(ctx, ctx->unstuffed.ensure((size_t)unstuffedCap));
+    const int64_t tiles = (g.totalBlocks + 255) / 256 * images;
+    HIP_TRY(ctx, ctx->tileState.ensure((size_t)(tiles + 1) * 8));
     EntropyWorkspace& ws = ctx->ws;
-    ws.bitLen = (uint32_t*)ctx->bitLen.p;
-    ws.bitOff = (unsigned long long*)ctx->bitOff.p;
-    ws.ivBytes = (unsigned long long*)ctx->ivBytes.p;
     ws.ivOff = (unsigned long long*)ctx->ivOff.p;
     ws.ffCount = (uint32_t*)ctx->ffCount.p;
     ws.ffOff = (unsigned long long*)ctx->ffOff.p;
@@ -267,11 +263,23 @@ int ensure_workspace(jpeg_hip_ctx* ctx, int images = 1) {
     ws.unstuffed = (uint8_t*)ctx->unstuffed.p;
     ws.unstuffedCap = unstuffedCap;
     ws.maxChunks = maxChunks;
+    ws.tileState = (unsigned long long*)ctx->tileState.p;
+    ws.streamBound = -1;
     return JPEG_HIP_OK;
 }
 
 void mark(jpeg_hip_ctx* ctx, int i) {
     if (ctx->profiling) (void)hipEventRecord(ctx->ev[i], ctx->stream);
+}
+
+// Bits that tables spend on the symbols counted in hist[4][256]: code length plus the
+// amplitude bits the symbol announces (the category for DC, the low nibble for AC).
+int64_t coded_bits(const uint64_t* hist, const uint8_t lengths[4][256]) {
+    int64_t bits = 0;
+    for (int t = 0; t < 4; ++t)
+        for (int s = 0; s < 256; ++s)
+            if (hist[t * 256 + s]) bits += (int64_t)hist[t * 256 + s] * (lengths[t][s] + (t < 2 ? s : (s & 15)));
+    return bits;
 }
 
 int install_tables(jpeg_hip_ctx* ctx) {
@@ -282,6 +290,7 @@ int install_tables(jpeg_hip_ctx* ctx) {
                                 ctx->stream));
     ctx->hasTables = true;
     ctx->stagedScanLen = -1;
+    ctx->streamBits = -1;
     return JPEG_HIP_OK;
 }
 
@@ -295,7 +304,9 @@ int build_tables(jpeg_hip_ctx* ctx, const uint64_t* hist) {
     }
     auto t1 = std::chrono::steady_clock::now();
     ctx->times[3] = std::chrono::duration<float, std::milli>(t1 - t0).count();
-    return install_tables(ctx);
+    const int st = install_tables(ctx);
+    ctx->streamBits = coded_bits(hist, ctx->lengths);   // hist covers at least this band's symbols
+    return st;
 }
 
 // Runs the entropy kernels and reads the length back.  prefix: bytes already placed at
@@ -303,6 +314,8 @@ int build_tables(jpeg_hip_ctx* ctx, const uint64_t* hist) {
 int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capacity, int writeEoi, int64_t* outLen) {
     mark(ctx, 3);
     ctx->kg.writeEoi = writeEoi;
+    // Padding (< 1 byte) and a marker per interval on top of the coded bits, EOI, slack.
+    ctx->ws.streamBound = ctx->streamBits < 0 ? -1 : ctx->streamBits / 8 + 3 * ctx->geo.intervals + 2 + 64;
     HIP_TRY(ctx, launch_entropy(ctx->kg, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, d_out,
                                 prefix, capacity, writeEoi, ctx->stream));
     mark(ctx, 4);
@@ -315,6 +328,7 @@ int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capac
         if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->times[1] = ms;
         if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->times[2] = ms;
     }
+    if (ctx->pin->result[1] & 2) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer's tiles lost their chain");
     if (ctx->pin->result[1] != 0) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "output buffer is too small for the scan");
     *outLen = (int64_t)ctx->pin->result[0];
     return JPEG_HIP_OK;
@@ -405,9 +419,9 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->bitLen, &ctx->bitOff,
-                      &ctx->ivBytes, &ctx->ivOff, &ctx->ffCount, &ctx->ffOff, &ctx->scanTmp, &ctx->result,
-                      &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart};
+    DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->ffOff, &ctx->scanTmp, &ctx->result,
+                      &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart,
+                      &ctx->tileState};
     for (DevBuf* b : bufs) b->release();
     HostBuf* hbufs[] = {&ctx->hostHist, &ctx->hostTables, &ctx->hostHdr, &ctx->hostHdrLen, &ctx->hostOffsets};
     for (HostBuf* b : hbufs) b->release();
@@ -705,9 +719,10 @@ constexpr int64_t kBatchMaxBlocks = 12 << 20;    // blocks per pass: 1.5 GiB of 
 
 // Huffman tables and headers of images [k0, k1) of a pass, from their histograms.
 void batch_tables_worker(const jpeg_hip_ctx* ctx, int k0, int k1, const uint64_t* hist, uint32_t* tables, uint8_t* hdr,
-                         uint32_t* hdrLen, int* status) {
+                         uint32_t* hdrLen, int* status, int64_t* bits) {
     uint8_t lengths[4][256];
     uint16_t codes[4][256];
+    *bits = 0;
     for (int k = k0; k < k1; ++k) {
         const uint64_t* h = hist + (size_t)k * 1024;
         for (int t = 0; t < 4; ++t) {
@@ -726,6 +741,7 @@ void batch_tables_worker(const jpeg_hip_ctx* ctx, int k0, int k1, const uint64_t
             return;
         }
         hdrLen[k] = (uint32_t)n;
+        *bits += coded_bits(h, lengths);
     }
 }
 
@@ -756,16 +772,17 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     int workers = (int)(hw == 0 ? 1 : (hw > 16 ? 16 : hw));
     if (workers > (n + 3) / 4) workers = (n + 3) / 4;
     std::vector<int> status((size_t)workers, JPEG_HIP_OK);
+    std::vector<int64_t> bits((size_t)workers, 0);
     std::vector<std::thread> pool;
     const int per = (n + workers - 1) / workers;
     for (int w = 1; w < workers; ++w) {
         const int a = w * per, b = a + per < n ? a + per : n;
         if (a >= b) break;
         pool.emplace_back(batch_tables_worker, ctx, a, b, (const uint64_t*)ctx->hostHist.p, (uint32_t*)ctx->hostTables.p,
-                          (uint8_t*)ctx->hostHdr.p, (uint32_t*)ctx->hostHdrLen.p, &status[(size_t)w]);
+                          (uint8_t*)ctx->hostHdr.p, (uint32_t*)ctx->hostHdrLen.p, &status[(size_t)w], &bits[(size_t)w]);
     }
     batch_tables_worker(ctx, 0, per < n ? per : n, (const uint64_t*)ctx->hostHist.p, (uint32_t*)ctx->hostTables.p,
-                        (uint8_t*)ctx->hostHdr.p, (uint32_t*)ctx->hostHdrLen.p, &status[0]);
+                        (uint8_t*)ctx->hostHdr.p, (uint32_t*)ctx->hostHdrLen.p, &status[0], &bits[0]);
     for (auto& t : pool) t.join();
     for (int st : status)
         if (st != JPEG_HIP_OK) return fail(ctx, st, "Huffman tables or headers of a batch image could not be built");
@@ -782,6 +799,9 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     bo.hdrLen = (const uint32_t*)ctx->batchHdrLen.p;
     bo.hdrPitch = kBatchHeaderPitch;
     bo.ffStart = (unsigned long long*)ctx->batchFfStart.p;
+    int64_t totalBits = 0;
+    for (int64_t v : bits) totalBits += v;
+    ctx->ws.streamBound = totalBits / 8 + 3 * (int64_t)n + 2 + 64;
     mark(ctx, 3);
     HIP_TRY(ctx, launch_entropy_batch(k, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, bo, ctx->stream));
     mark(ctx, 4);
@@ -796,6 +816,7 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
         if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->times[1] += ms;
         if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->times[2] += ms;
     }
+    if (off[2 * (n + 1) + 1] & 2) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer's tiles lost their chain");
     bool overflow = off[2 * (n + 1) + 1] != 0;
     const uint32_t* hdrLen = (const uint32_t*)ctx->hostHdrLen.p;
     for (int i = 0; i < n; ++i) {

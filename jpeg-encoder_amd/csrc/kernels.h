@@ -49,17 +49,17 @@ struct BatchOutput {
 
 // Device workspace of the entropy stage (all sizes fixed by the geometry).
 struct EntropyWorkspace {
-    uint32_t* bitLen;            // [totalBlocks]
-    unsigned long long* bitOff;  // [totalBlocks + 1]
-    unsigned long long* ivBytes; // [intervals]
-    unsigned long long* ivOff;   // [intervals + 1]
+    unsigned long long* ivOff;   // [intervals + 1]: byte offset of every interval in the unstuffed stream
     uint32_t* ffCount;           // [maxChunks]
     unsigned long long* ffOff;   // [maxChunks + 1]
     unsigned long long* scanTmp; // scratch for the scans
-    unsigned long long* result;  // [4]: stuffed length, overflow flag, unstuffed bytes, 0xFF count
+    unsigned long long* result;  // [4]: stuffed length, error flags (1: output too small, 2: tile chain broken),
+                                 //      unstuffed bytes, number of 4 KiB chunks
     uint8_t* unstuffed;          // [unstuffedCap]
     long long unstuffedCap;
     long long maxChunks;
+    unsigned long long* tileState;   // [tiles + 1] of the single-pass bit writer (tiles of 256 blocks)
+    long long streamBound;           // upper bound of the unstuffed stream in bytes, or < 0 when unknown
 };
 
 constexpr int kStuffChunk = 4096;   // unstuffed bytes handled by one workgroup pass
@@ -70,8 +70,8 @@ hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qt
 // Symbol histograms (uint64[4][256] per image of the batch); d_hist is cleared first.
 hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, unsigned long long* d_hist, hipStream_t s);
 
-// Bit lengths, offsets, bit writer and byte stuffing.  d_tables: uint32[4][256], entry =
-// (length << 16) | code.  Scan bytes go to d_out + prefixLen; EOI is appended when
+// Single-pass bit writer (lengths, positions, bits) and byte stuffing.  d_tables:
+// uint32[4][256], entry = (length << 16) | code.  Scan bytes go to d_out + prefixLen; EOI is appended when
 // writeEoi is set.  ws.result[0] receives prefixLen + scan bytes (+ 2 with EOI);
 // ws.result[1] is non-zero when outCapacity was too small.
 hipError_t launch_entropy(const KGeom& g, const int16_t* d_coef, const uint32_t* d_tables, const EntropyWorkspace& ws,

@@ -649,6 +649,7 @@ hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, 
 }
 
 // ---- bit lengths -------------------------------------------------------------------------
+// Bits a block occupies in the stream under the given tables.
 struct LengthVisitor {
     const u32* dcTab;
     const u32* acTab;
@@ -658,60 +659,6 @@ struct LengthVisitor {
     __device__ __forceinline__ void zrl(int n) { bits += n * (acTab[0xF0] >> 16); }
     __device__ __forceinline__ void eob() { bits += acTab[0] >> 16; }
 };
-
-// With kTileSums the kernel also produces the per-tile sums (tiles of kScanTile consecutive
-// blocks) that the offset scan starts from, which saves that scan's first pass; a
-// workgroup then owns whole tiles, so this form is for images with many tiles.
-constexpr int kLenTile = 2048;   // == kScanTile
-
-template <bool kTileSums>
-__global__ __launch_bounds__(kEntThreads) void k_bit_lengths(KGeom g, const int16_t* __restrict__ coef,
-                                                             const u32* __restrict__ tables,
-                                                             u32* __restrict__ bitLen, u64* __restrict__ tileSums) {
-    __shared__ u32 tab[4 * 256];
-    __shared__ u32 partial[kEntThreads / 64];
-    // blockIdx.y: image of the batch (always 0 for the tile-sum form), with its own tables.
-    const u32* myTables = tables + (long long)blockIdx.y * 1024;
-    for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = myTables[i];
-    __syncthreads();
-    constexpr int kSpan = kTileSums ? kLenTile : kEntThreads;   // blocks per workgroup pass
-    const long long first = (long long)blockIdx.y * g.blocksPerImage;
-    const long long count = kTileSums ? g.totalBlocks : g.blocksPerImage;
-    const long long spans = (count + kSpan - 1) / kSpan;
-    for (long long span = blockIdx.x; span < spans; span += gridDim.x) {
-        u32 sum = 0;
-#pragma unroll 1
-        for (int it = 0; it < kSpan / kEntThreads; ++it) {
-            const long long bl = span * kSpan + it * kEntThreads + threadIdx.x;
-            const long long b = first + bl;
-            if (bl < count) {
-                const long long m = b / g.bpm;
-                const int k = (int)(b - m * g.bpm);
-                const int c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
-                u32 w[32];
-                load_block(coef, b, w);
-                const int pred = dc_predictor(g, coef, b, m, k, c);
-                const int t = c == 0 ? 0 : 1;
-                LengthVisitor vis{tab + 256 * t, tab + 512 + 256 * t, 0u};
-                walk_block(w, pred, vis);
-                bitLen[b] = vis.bits;
-                sum += vis.bits;
-            }
-        }
-        if (kTileSums) {
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
-            if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = sum;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                u64 total = 0;
-                for (int i = 0; i < kEntThreads / 64; ++i) total += partial[i];
-                tileSums[span] = total;
-            }
-            __syncthreads();
-        }
-    }
-}
 
 // ---- exclusive scans ---------------------------------------------------------------------
 // out[i] = sum of in[0..i), out[n] = total.  n is read from device memory when dN is set.
@@ -876,66 +823,6 @@ __device__ __forceinline__ bool interval_has_eoi(const KGeom& g, long long k) {
     return g.writeEoi && (g.batch > 1 || k == g.intervals - 1);
 }
 
-__global__ void k_interval_bytes(KGeom g, const u64* __restrict__ bitOff, u64* __restrict__ ivBytes) {
-    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= g.intervals) return;
-    const long long b0 = k * g.mcusPerInterval * g.bpm;
-    long long b1 = (k + 1) * g.mcusPerInterval * g.bpm;
-    if (b1 > g.totalBlocks) b1 = g.totalBlocks;
-    u64 n = ((bitOff[b1] - bitOff[b0] + 7) >> 3) + interval_marker_bytes(g, k);
-    if (interval_has_eoi(g, k)) n += 2;
-    ivBytes[k] = n;
-}
-
-// Interval sizes, their offsets and the stream totals in one launch (one workgroup), for up
-// to kSmallScanLimit intervals.
-__global__ __launch_bounds__(kScanThreads) void k_intervals_small(KGeom g, const u64* __restrict__ bitOff,
-                                                                  u64* __restrict__ ivOff, u64* __restrict__ result) {
-    __shared__ u64 lds[4];
-    const long long perInterval = g.mcusPerInterval * g.bpm;
-    u64 carry = 0;
-    for (long long k0 = 0; k0 < g.intervals; k0 += kScanThreads) {
-        const long long k = k0 + threadIdx.x;
-        u64 n = 0;
-        if (k < g.intervals) {
-            const long long b0 = k * perInterval;
-            long long b1 = b0 + perInterval;
-            if (b1 > g.totalBlocks) b1 = g.totalBlocks;
-            n = ((bitOff[b1] - bitOff[b0] + 7) >> 3) + interval_marker_bytes(g, k);
-            if (interval_has_eoi(g, k)) n += 2;
-        }
-        u64 total;
-        const u64 ex = block_exclusive_scan(n, lds, total);
-        if (k < g.intervals) ivOff[k] = carry + ex;
-        carry += total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        ivOff[g.intervals] = carry;
-        result[2] = carry;
-        result[1] = 0;
-        result[3] = (carry + kStuffChunk - 1) / kStuffChunk;
-    }
-}
-
-// Totals for the general path (many intervals), after the interval offsets were scanned.
-__global__ void k_publish_totals(const u64* __restrict__ ivOff, long long intervals, u64* __restrict__ result) {
-    const u64 bytes = ivOff[intervals];
-    result[2] = bytes;
-    result[1] = 0;
-    result[3] = (bytes + kStuffChunk - 1) / kStuffChunk;
-}
-
-// Clears the part of the unstuffed buffer the bit writer will OR into.
-__global__ void k_prepare_unstuffed(const u64* __restrict__ result, uint4* __restrict__ buf, long long capBytes) {
-    const u64 bytes = result[2];
-    long long clear = (long long)((bytes + kStuffChunk - 1) / kStuffChunk) * kStuffChunk + 16;
-    if (clear > capBytes) clear = capBytes;
-    const long long n16 = clear / 16;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x)
-        buf[i] = make_uint4(0, 0, 0, 0);
-}
-
 // ---- bit writer ------------------------------------------------------------------------
 // One thread per block appends its codes MSB first.  A workgroup's 256 blocks cover one
 // contiguous bit range; it is assembled in LDS (ds_or for the words two blocks share) and
@@ -996,58 +883,220 @@ struct EmitVisitor {
     }
 };
 
-__global__ __launch_bounds__(kEntThreads) void k_emit_bits(KGeom g, const int16_t* __restrict__ coef,
-                                                           const u32* __restrict__ tables,
-                                                           const u64* __restrict__ bitOff,
-                                                           const u64* __restrict__ ivOff, u32* __restrict__ words) {
+// ---- single-pass bit writer --------------------------------------------------------------
+// Bit lengths, stream positions and the bit writer in one pass over the coefficients.  A
+// tile is 256 consecutive blocks of one image.  The stream position after a block is a
+// function of the position before it: P + bits, or, behind the last block of a restart
+// interval, roundup8(P + bits) + the marker that follows (the next interval's RSTn, or EOI).
+// A run of blocks composes to "P + h" (no interval ends inside) or "roundup8(P + h) + m",
+// an associative summary, so tiles chain with a decoupled look-back: every tile publishes
+// its summary as soon as its lengths are known, then its first wave reads the summaries of
+// its predecessors back to the nearest tile whose absolute position is already known.
+// Tiles take their numbers from a counter, so every predecessor of a running tile is
+// running or finished and the wait always ends.
+struct PosSummary {
+    u32 x;   // h, bit 31: an interval ends inside
+    u32 y;   // m
+};
+
+__device__ __forceinline__ PosSummary pos_combine(PosSummary a, PosSummary b) {   // a precedes b
+    PosSummary r;
+    if ((a.x >> 31) == 0) {
+        r.x = a.x + b.x;
+        r.y = b.y;
+    } else {
+        const u32 bh = b.x & 0x7fffffffu;
+        r.x = a.x;
+        r.y = (b.x >> 31) ? ((a.y + bh + 7u) & ~7u) + b.y : a.y + bh;
+    }
+    return r;
+}
+
+__device__ __forceinline__ u64 pos_apply(PosSummary s, u64 p) {
+    const u32 h = s.x & 0x7fffffffu;
+    return (s.x >> 31) ? ((p + h + 7) & ~7ull) + s.y : p + h;
+}
+
+constexpr u64 kTileAggregate = 1ull << 62, kTilePosition = 2ull << 62, kTilePayload = (1ull << 62) - 1;
+constexpr int kLookBackSpins = 1 << 18;
+
+__device__ __forceinline__ PosSummary shfl_down_summary(PosSummary v, int d, int lane) {
+    PosSummary o;
+    o.x = __shfl_down(v.x, d, 64);
+    o.y = __shfl_down(v.y, d, 64);
+    if (lane + d >= 64) o.x = o.y = 0;
+    return o;
+}
+
+// Absolute bit position at which tile `tile` starts; p0 is the position of the stream's
+// first block.  Called by all 64 lanes of one wave.  Returns false if a predecessor never
+// reported (cannot happen with ordered tile numbers; bounded so a fault cannot hang the GPU).
+__device__ __forceinline__ bool look_back(const u64* state, long long tile, u64 p0, u64& position) {
+    const int lane = threadIdx.x & 63;
+    PosSummary acc = {0u, 0u};
+    int spins = 0;
+    for (long long base = tile - 1;; base -= 64) {
+        const long long idx = base - lane;
+        u64 st = idx < 0 ? (kTilePosition | p0) : __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__ballot((st >> 62) == 0) != 0) {
+            if (++spins > kLookBackSpins) return false;
+            __builtin_amdgcn_s_sleep(2);
+            if ((st >> 62) == 0) st = __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const u64 known = __ballot((st >> 62) == 2);
+        const int nearest = known ? __builtin_ctzll(known) : 64;   // lanes below it hold summaries only
+        PosSummary v = {0u, 0u};
+        if (lane < nearest) {
+            v.x = (u32)((st & kTilePayload) >> 30);
+            v.y = (u32)(st & 0x3fffffffu);
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) v = pos_combine(shfl_down_summary(v, d, lane), v);   // older tiles first
+        PosSummary window;
+        window.x = __shfl(v.x, 0, 64);
+        window.y = __shfl(v.y, 0, 64);
+        acc = pos_combine(window, acc);
+        if (known) {
+            const u64 p = __shfl(st & kTilePayload, nearest, 64);
+            position = pos_apply(acc, p);
+            return true;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int16_t* __restrict__ coef,
+                                                             const u32* __restrict__ tables, u64* __restrict__ state,
+                                                             u64* __restrict__ ivOff, u64* __restrict__ result,
+                                                             u32* __restrict__ words) {
     __shared__ u32 tab[4 * 256];
     __shared__ u32 stage[kEmitStageWords];
     __shared__ u64 span[2];
-    const long long blocksPerInterval = g.mcusPerInterval * g.bpm;
-    // blockIdx.y: image of the batch; a workgroup's blocks all belong to one image.
-    const long long bl = (long long)blockIdx.x * kEntThreads + threadIdx.x;
-    const long long b = (long long)blockIdx.y * g.blocksPerImage + bl;
+    __shared__ PosSummary waveSum[kEntThreads / 64];
+    __shared__ u64 tileStart;
+    __shared__ long long tileNo;
+    const long long tilesPerImage = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
+    const long long tiles = tilesPerImage * g.batch;
+    u64* counter = state + tiles;
+    if (threadIdx.x == 0) tileNo = (long long)atomicAdd((unsigned long long*)counter, 1ull);
+    __syncthreads();
+    const long long tile = tileNo;
+    const long long image = tile / tilesPerImage;
+    const long long bl = (tile - image * tilesPerImage) * kEntThreads + threadIdx.x;
+    const long long b = image * g.blocksPerImage + bl;
     const bool active = bl < g.blocksPerImage;
-    long long m = 0;
-    int k = 0, c = 0, padBits = 0, pred = 0;
-    u32 leadMarker = 0;
-    bool tailEoi = false;
-    u64 pos = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long blocksPerInterval = g.mcusPerInterval * g.bpm;
+
     u32 w[32];
+    if (active) load_block(coef, b, w);   // in flight while the tables are staged
+    const u32* myTables = tables + image * 1024;
+    for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = myTables[i];
+    __syncthreads();
+
+    long long iv = 0;
+    int c = 0, pred = 0;
+    bool firstOfInterval = false, lastOfInterval = false;
+    PosSummary mine = {0u, 0u};
+    u32 bits = 0;
     if (active) {
-        // Coefficients first: their latency overlaps the offset arithmetic and the barriers.
-        load_block(coef, b, w);
-        m = b / g.bpm;
-        k = (int)(b - m * g.bpm);
+        const long long m = b / g.bpm;
+        const int k = (int)(b - m * g.bpm);
         c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
         pred = dc_predictor(g, coef, b, m, k, c);
-        const long long iv = m / g.mcusPerInterval;
+        iv = m / g.mcusPerInterval;
         const long long ivFirstBlock = iv * blocksPerInterval;
-        const int mk = interval_marker_bytes(g, iv);
-        u64 end;
-        if (b == ivFirstBlock) {
-            pos = ivOff[iv] * 8;
-            end = pos + 8 * mk + (bitOff[b + 1] - bitOff[b]);
-            if (mk) leadMarker = 0xffd0u + (u32)((g.firstInterval + iv - 1) & 7);
-        } else {
-            pos = (ivOff[iv] + mk) * 8 + (bitOff[b] - bitOff[ivFirstBlock]);
-            end = pos + (bitOff[b + 1] - bitOff[b]);
+        long long ivEnd = ivFirstBlock + blocksPerInterval;
+        if (ivEnd > g.totalBlocks) ivEnd = g.totalBlocks;
+        firstOfInterval = b == ivFirstBlock;
+        lastOfInterval = b == ivEnd - 1;
+        const int t = c == 0 ? 0 : 1;
+        LengthVisitor len{tab + 256 * t, tab + 512 + 256 * t, 0u};
+        walk_block(w, pred, len);
+        bits = len.bits;
+        mine.x = bits;
+        if (lastOfInterval) {
+            mine.x |= 0x80000000u;
+            mine.y = iv + 1 < g.intervals ? 8u * (u32)interval_marker_bytes(g, iv + 1) : 0u;
+            if (interval_has_eoi(g, iv)) mine.y += 16u;
         }
-        long long last = ivFirstBlock + blocksPerInterval;
-        if (last > g.totalBlocks) last = g.totalBlocks;
-        if (b == last - 1) {   // pad the interval to a byte boundary (BitBuffer.cpp:12-16)
+    }
+    // Inclusive scan of the summaries over the workgroup.
+    PosSummary inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        PosSummary o;
+        o.x = __shfl_up(inc.x, d, 64);
+        o.y = __shfl_up(inc.y, d, 64);
+        if (lane >= d) inc = pos_combine(o, inc);
+    }
+    if (lane == 63) waveSum[wave] = inc;
+    __syncthreads();
+    PosSummary before = {0u, 0u}, whole = {0u, 0u};
+#pragma unroll
+    for (int i = 0; i < kEntThreads / 64; ++i) {
+        if (i < wave) before = pos_combine(before, waveSum[i]);
+        whole = pos_combine(whole, waveSum[i]);
+    }
+    PosSummary excl;
+    excl.x = __shfl_up(inc.x, 1, 64);
+    excl.y = __shfl_up(inc.y, 1, 64);
+    if (lane == 0) excl.x = excl.y = 0;
+    excl = pos_combine(before, excl);
+
+    const u64 p0 = 8ull * (u64)interval_marker_bytes(g, 0);
+    if (wave == 0) {
+        if (tile > 0 && lane == 0)
+            __hip_atomic_store(state + tile, kTileAggregate | ((u64)whole.x << 30) | whole.y, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        u64 start = p0;
+        bool ok = true;
+        if (tile > 0) ok = look_back(state, tile, p0, start);
+        if (lane == 0) {
+            if (!ok) {
+                start = p0;
+                result[1] = 2;
+            }
+            __hip_atomic_store(state + tile, kTilePosition | pos_apply(whole, start), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            tileStart = start;
+        }
+    }
+    __syncthreads();
+
+    u64 pos = 0;
+    int padBits = 0;
+    u32 leadMarker = 0;
+    bool tailEoi = false;
+    if (active) {
+        pos = pos_apply(excl, tileStart);
+        u64 begin = pos;
+        u64 end = pos + bits;
+        if (firstOfInterval) {
+            const int mk = interval_marker_bytes(g, iv);
+            if (mk) {
+                leadMarker = 0xffd0u + (u32)((g.firstInterval + iv - 1) & 7);
+                begin -= 16;
+            }
+            ivOff[iv] = begin >> 3;
+        }
+        if (lastOfInterval) {   // pad the interval to a byte boundary (BitBuffer.cpp:12-16)
             padBits = (int)((8 - (end & 7)) & 7);
             end += padBits;
             if (interval_has_eoi(g, iv)) {
                 tailEoi = true;
                 end += 16;
             }
+            if (b == g.totalBlocks - 1) {
+                const u64 bytes = end >> 3;
+                ivOff[g.intervals] = bytes;
+                result[2] = bytes;
+                result[3] = (bytes + kStuffChunk - 1) / kStuffChunk;
+            }
         }
-        if (threadIdx.x == 0) span[0] = pos;
+        if (threadIdx.x == 0) span[0] = begin;
         if (threadIdx.x == kEntThreads - 1 || bl == g.blocksPerImage - 1) span[1] = end;
+        pos = begin;
     }
-    const u32* myTables = tables + (long long)blockIdx.y * 1024;
-    for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = myTables[i];
     __syncthreads();
     const u64 wordBase = span[0] >> 5;
     const u64 nWords = ((span[1] + 31) >> 5) - wordBase;
@@ -1293,38 +1342,20 @@ __global__ __launch_bounds__(256) void k_copy_headers(BatchOutput bo) {
 static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const u32* d_tables,
                                     const EntropyWorkspace& ws, uint8_t* d_out, long long prefixLen,
                                     long long outCapacity, const BatchOutput* bo, hipStream_t s) {
-    const long long tiles = (g.totalBlocks + kLenTile - 1) / kLenTile;
-    const bool fusedSums = g.batch == 1 && tiles >= 1024;   // enough tiles to fill the chip with whole-tile workgroups
     hipError_t e;
-    if (fusedSums) {
-        const unsigned lenGrid = (unsigned)(tiles > 2048 ? 2048 : tiles);
-        hipLaunchKernelGGL(k_bit_lengths<true>, dim3(lenGrid), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.bitLen,
-                           ws.scanTmp);
-    } else {
-        long long lenGrid = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
-        const long long cap = g.batch > 1 ? (8192 / g.batch > 8 ? 8192 / g.batch : 8) : 4096;
-        if (lenGrid > cap) lenGrid = cap;
-        hipLaunchKernelGGL(k_bit_lengths<false>, dim3((unsigned)lenGrid, (unsigned)g.batch), dim3(kEntThreads), 0, s, g,
-                           d_coef, d_tables, ws.bitLen, ws.scanTmp);
-    }
-    e = exclusive_scan<u32>(ws.bitLen, g.totalBlocks, nullptr, g.totalBlocks, ws.scanTmp, ws.bitOff, s, fusedSums);
+    const long long tilesPerImage = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
+    const long long tileCount = tilesPerImage * g.batch;
+    // The bit writer ORs into the stream, so the part it can reach starts out as zeros.
+    long long zero = ws.streamBound < 0 ? ws.unstuffedCap : (ws.streamBound + kStuffChunk + 63) / 16 * 16;
+    if (zero > ws.unstuffedCap) zero = ws.unstuffedCap;
+    e = hipMemsetAsync(ws.unstuffed, 0, (size_t)zero, s);
     if (e != hipSuccess) return e;
-    if (g.intervals <= kSmallScanLimit) {
-        hipLaunchKernelGGL(k_intervals_small, dim3(1), dim3(kScanThreads), 0, s, g, ws.bitOff, ws.ivOff, ws.result);
-    } else {
-        hipLaunchKernelGGL(k_interval_bytes, dim3((unsigned)((g.intervals + 255) / 256)), dim3(256), 0, s, g, ws.bitOff,
-                           ws.ivBytes);
-        e = exclusive_scan<u64>(ws.ivBytes, g.intervals, nullptr, g.intervals, ws.scanTmp, ws.ivOff, s);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_publish_totals, dim3(1), dim3(1), 0, s, ws.ivOff, g.intervals, ws.result);
-    }
-    long long zeroGrid = ws.unstuffedCap / (16 * 256 * 8);
-    zeroGrid = zeroGrid < 1 ? 1 : (zeroGrid > 1024 ? 1024 : zeroGrid);
-    hipLaunchKernelGGL(k_prepare_unstuffed, dim3((unsigned)zeroGrid), dim3(256), 0, s, ws.result, (uint4*)ws.unstuffed,
-                       ws.unstuffedCap);
-    const long long emitGrid = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
-    hipLaunchKernelGGL(k_emit_bits, dim3((unsigned)emitGrid, (unsigned)g.batch), dim3(kEntThreads), 0, s, g, d_coef,
-                       d_tables, ws.bitOff, ws.ivOff, (u32*)ws.unstuffed);
+    e = hipMemsetAsync(ws.tileState, 0, (size_t)(tileCount + 1) * 8, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ws.result, 0, 4 * 8, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_encode_bits, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.tileState,
+                       ws.ivOff, ws.result, (u32*)ws.unstuffed);
     long long chunkGrid = ws.maxChunks < 2048 ? ws.maxChunks : 2048;
     if (chunkGrid < 1) chunkGrid = 1;
     hipLaunchKernelGGL(k_count_ff, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.result,
