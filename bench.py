@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="16k_420_q90", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU and step (batch workload)")
+    ap.add_argument("--standard-huffman", action="store_true",
+                    help="Annex K tables instead of per-image optimised ones: no histogram pass, no host step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -127,6 +129,8 @@ def main():
         params = B.make_params(width, height, scheme, qt)
         lay = B.compute_layout(params)
         y0, y1 = 0, height
+    if args.standard_huffman:
+        params.standard_huffman = 1
     stride = width * 3
     if batch:
         image_stride = stride * height
@@ -141,7 +145,7 @@ def main():
     # Output capacity: the worst case bound is huge; 1.5 bytes per pixel of the band plus
     # slack covers every workload here (noise at q=100 needs about 1.1 B/px in 4:2:0 and
     # 2.9 B/px in 4:4:4, which gets its own bound).
-    per_px = 3.2 if kind == "noise" else 1.0
+    per_px = 3.2 if kind == "noise" else (0.5 if args.standard_huffman else 1.0)
     cap = int((y1 - y0 + lay.mcu_height) * lay.padded_width * per_px) + (1 << 20)
     out = torch.empty(cap * max(batch, 1), dtype=torch.uint8, device=dev)
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
@@ -152,7 +156,7 @@ def main():
             lens = ctx.encode_batch(rgb.data_ptr(), B.RGB8, stride, image_stride, batch, params, out.data_ptr(), cap)
             return int(lens.sum())
         ctx.analyze_band(rgb.data_ptr(), B.RGB8, stride, params, hist.data_ptr())
-        if world > 1:
+        if world > 1 and not args.standard_huffman:
             cur = torch.cuda.current_stream()
             cur.wait_stream(ext)
             dist.all_reduce(hist)
@@ -199,6 +203,7 @@ def main():
             "config": {"workload": desc, "name": args.workload, "width": width, "height": height,
                        "sampling": sname, "quality": quality,
                        "restart_interval_mcus": int(params.restart_interval),
+                       "huffman": "standard (Annex K)" if args.standard_huffman else "optimised per image",
                        "frames_per_gpu_per_step": batch or None,
                        "parallelism": ("frames-per-gpu x%d" if batch else "band-per-gpu x%d") % world,
                        "jpeg_bytes_rank0": int(n_out)},

@@ -67,6 +67,12 @@ enum {
  *   sharded over several GPUs; both 0 selects the whole image.  A band must start on a
  *   restart-interval boundary.  The RGB pointer handed to the encode calls addresses
  *   image row mcu_row_begin * (MCU height).  No counterpart in the reference.
+ * standard_huffman:
+ *   0: Huffman tables optimised per image from its symbol histograms, as the reference
+ *   always does (Encoder::createHuffmanTable, Encoder.cpp:368-416).  1: the typical tables
+ *   of ITU-T T.81 Annex K.3 (K.3-K.6); the histogram pass, its read-back and the host table
+ *   build are skipped, so an encode never waits for the host.  RGB8 input only (the tables
+ *   have codes for 8-bit precision symbols only).  No counterpart in the reference.
  */
 typedef struct jpeg_hip_params {
     int32_t width;
@@ -77,6 +83,7 @@ typedef struct jpeg_hip_params {
     int32_t pad_ones;
     int32_t mcu_row_begin;
     int32_t mcu_row_end;
+    int32_t standard_huffman;
 } jpeg_hip_params;
 
 /* Derived sizes (Image::Image, Image.cpp:6-16; Encoder::createBlocks, Encoder.cpp:168-227). */
@@ -164,6 +171,12 @@ int jpeg_hip_histograms_host(jpeg_hip_ctx* ctx, uint64_t* h_hist);
  * package-merge code lengths (<= 16) and right-growing codes.  Pure host function.
  * lengths[s] == 0 marks an unused symbol; codes are right aligned. */
 int jpeg_hip_huffman_from_histogram(const uint64_t counts[256], uint8_t lengths[256], uint16_t codes[256]);
+
+/* The typical Huffman tables of ITU-T T.81 Annex K.3 in the layout of jpeg_hip_get_huffman:
+ * [0] DC luminance (table K.3), [1] DC chrominance (K.4), [2] AC luminance (K.5), [3] AC
+ * chrominance (K.6), with the canonical codes of Annex C.  No counterpart in the reference
+ * (which always optimises); see jpeg_hip_params.standard_huffman. */
+int jpeg_hip_standard_huffman(uint8_t lengths[4][256], uint16_t codes[4][256]);
 
 /* DefineHuffmannTable segment (JPEGSegments.h:102-140, 203-207) for a table.  Returns the
  * number of bytes written, or a negative status. */

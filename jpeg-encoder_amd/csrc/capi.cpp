@@ -37,6 +37,7 @@ int make_geometry(const jpeg_hip_params& p, Geometry& g) {
         }
     }
     if (p.restart_interval < 0 || p.restart_interval > 65535) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (p.standard_huffman != 0 && p.standard_huffman != 1) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     g.width = p.width;
     g.height = p.height;
     g.stepW = lcm_i(lcm_i(g.wf[0], g.wf[1]), g.wf[2]) * 8;   // SamplingScheme.h:36-38
@@ -193,6 +194,8 @@ int check_pixels(jpeg_hip_ctx* ctx, const void* p, int fmt, int64_t stride) {
         return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "row stride is smaller than one row of pixels");
     if (fmt == JPEG_HIP_RGBF32 && (stride % 4 != 0 || ((uintptr_t)p & 3) != 0))
         return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "float pixels must be 4-byte aligned");
+    if (fmt == JPEG_HIP_RGBF32 && ctx->prm.standard_huffman)
+        return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "the standard Huffman tables cover 8-bit pixels only");
     return JPEG_HIP_OK;
 }
 
@@ -230,6 +233,7 @@ void fill_kgeom(jpeg_hip_ctx* ctx) {
     k.mcusPerImage = g.nMcu;
     k.blocksPerImage = g.totalBlocks;
     k.imageStrideBytes = 0;
+    k.tableStride = 1024;
 }
 
 // Workspace for `images` images of the current geometry (1 outside batch mode; in a batch
@@ -309,13 +313,19 @@ int build_tables(jpeg_hip_ctx* ctx, const uint64_t* hist) {
     return st;
 }
 
+int install_standard_tables(jpeg_hip_ctx* ctx) {
+    standard_huffman(ctx->lengths, ctx->codes);
+    return install_tables(ctx);
+}
+
 // Runs the entropy kernels and reads the length back.  prefix: bytes already placed at
 // the start of d_out (headers).
 int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capacity, int writeEoi, int64_t* outLen) {
     mark(ctx, 3);
     ctx->kg.writeEoi = writeEoi;
     // Padding (< 1 byte) and a marker per interval on top of the coded bits, EOI, slack.
-    ctx->ws.streamBound = ctx->streamBits < 0 ? -1 : ctx->streamBits / 8 + 3 * ctx->geo.intervals + 2 + 64;
+    // Without histograms the output capacity bounds the stream: a longer one fails anyway.
+    ctx->ws.streamBound = ctx->streamBits < 0 ? capacity - prefix : ctx->streamBits / 8 + 3 * ctx->geo.intervals + 2 + 64;
     HIP_TRY(ctx, launch_entropy(ctx->kg, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, d_out,
                                 prefix, capacity, writeEoi, ctx->stream));
     mark(ctx, 4);
@@ -550,6 +560,12 @@ int jpeg_hip_huffman_from_histogram(const uint64_t counts[256], uint8_t lengths[
     return JPEG_HIP_OK;
 }
 
+int jpeg_hip_standard_huffman(uint8_t lengths[4][256], uint16_t codes[4][256]) {
+    if (!lengths || !codes) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    standard_huffman(lengths, codes);
+    return JPEG_HIP_OK;
+}
+
 int jpeg_hip_write_dht(const uint8_t lengths[256], const uint16_t codes[256], int table_id, int coefficient_type,
                        uint8_t* h_out, int capacity) {
     if (!lengths || !codes || !h_out) return JPEG_HIP_ERR_INVALID_ARGUMENT;
@@ -646,16 +662,21 @@ int jpeg_hip_analyze_band(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_forma
     if (st != JPEG_HIP_OK) return st;
     st = do_transform(ctx, JPEG_HIP_STAGE_ALL);
     if (st != JPEG_HIP_OK) return st;
+    if (ctx->prm.standard_huffman) {   // fixed tables: nothing to count
+        mark(ctx, 2);
+        return JPEG_HIP_OK;
+    }
     // A null d_hist keeps the histograms in the context's own buffer.
     return do_histograms(ctx, d_hist ? d_hist : (uint64_t*)ctx->hist.p);
 }
 
 int jpeg_hip_finish_band(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t* d_out, int64_t out_capacity,
                          int64_t* out_len) {
-    if (!ctx || !d_hist_sum || !d_out || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx || !d_out || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (!ctx->transformed) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "finish needs analyze");
+    if (!ctx->prm.standard_huffman && !d_hist_sum) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int st = fetch_hist_and_build(ctx, d_hist_sum);
+    int st = ctx->prm.standard_huffman ? install_standard_tables(ctx) : fetch_hist_and_build(ctx, d_hist_sum);
     if (st != JPEG_HIP_OK) return st;
     int64_t prefix = 0;
     st = place_headers(ctx, d_out, out_capacity, &prefix);
@@ -680,8 +701,12 @@ int jpeg_hip_encode_host(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format
     if (st != JPEG_HIP_OK) return st;
     st = do_transform(ctx, JPEG_HIP_STAGE_ALL);
     if (st != JPEG_HIP_OK) return st;
-    st = do_histograms(ctx, (uint64_t*)ctx->hist.p);
-    if (st != JPEG_HIP_OK) return st;
+    if (!params->standard_huffman) {
+        st = do_histograms(ctx, (uint64_t*)ctx->hist.p);
+        if (st != JPEG_HIP_OK) return st;
+    } else {
+        mark(ctx, 2);
+    }
     jpeg_hip_layout lay;
     st = jpeg_hip_compute_layout(params, &lay);
     if (st != JPEG_HIP_OK) return st;
@@ -762,6 +787,28 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     mark(ctx, 0);
     HIP_TRY(ctx, launch_transform(k, d_rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, ctx->stream));
     mark(ctx, 1);
+    const bool standard = ctx->prm.standard_huffman != 0;
+    int64_t totalBits = 0;
+    if (standard) {
+        // One table set and one header serve every image; nothing waits for the host.
+        mark(ctx, 2);
+        k.tableStride = 0;
+        uint8_t lengths[4][256];
+        uint16_t codes[4][256];
+        standard_huffman(lengths, codes);
+        uint32_t* tables = (uint32_t*)ctx->hostTables.p;
+        for (int t = 0; t < 4; ++t)
+            for (int s = 0; s < 256; ++s) tables[t * 256 + s] = ((uint32_t)lengths[t][s] << 16) | codes[t][s];
+        uint8_t* hdr = (uint8_t*)ctx->hostHdr.p;
+        const int hn = write_headers(ctx->prm, ctx->geo, lengths, codes, hdr, kBatchHeaderPitch);
+        if (hn < 0) return fail(ctx, hn, "header assembly failed");
+        uint32_t* hdrLen = (uint32_t*)ctx->hostHdrLen.p;
+        for (int i = 0; i < n; ++i) {
+            if (i > 0) memcpy(hdr + (size_t)i * kBatchHeaderPitch, hdr, (size_t)hn);
+            hdrLen[i] = (uint32_t)hn;
+        }
+        totalBits = -1;
+    } else {
     HIP_TRY(ctx, launch_histogram(k, (const int16_t*)ctx->coef.p, (unsigned long long*)ctx->hist.p, ctx->stream));
     mark(ctx, 2);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->hostHist.p, ctx->hist.p, (size_t)n * 1024 * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -787,8 +834,11 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     for (int st : status)
         if (st != JPEG_HIP_OK) return fail(ctx, st, "Huffman tables or headers of a batch image could not be built");
     ctx->times[3] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (int64_t v : bits) totalBits += v;
+    }
 
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->hostTables.p, (size_t)n * 1024 * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->hostTables.p, (size_t)(standard ? 1 : n) * 1024 * 4, hipMemcpyHostToDevice,
+                                ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->batchHdr.p, ctx->hostHdr.p, (size_t)n * kBatchHeaderPitch, hipMemcpyHostToDevice,
                                 ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->batchHdrLen.p, ctx->hostHdrLen.p, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -799,9 +849,8 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     bo.hdrLen = (const uint32_t*)ctx->batchHdrLen.p;
     bo.hdrPitch = kBatchHeaderPitch;
     bo.ffStart = (unsigned long long*)ctx->batchFfStart.p;
-    int64_t totalBits = 0;
-    for (int64_t v : bits) totalBits += v;
-    ctx->ws.streamBound = totalBits / 8 + 3 * (int64_t)n + 2 + 64;
+    // Without histograms the slots bound the stream: a longer one fails anyway.
+    ctx->ws.streamBound = totalBits < 0 ? (int64_t)n * slotBytes : totalBits / 8 + 3 * (int64_t)n + 2 + 64;
     mark(ctx, 3);
     HIP_TRY(ctx, launch_entropy_batch(k, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, bo, ctx->stream));
     mark(ctx, 4);

@@ -34,6 +34,7 @@ struct KGeom {
     long long mcusPerImage;
     long long blocksPerImage;
     long long imageStrideBytes;
+    int tableStride;             // entries between the Huffman table sets of consecutive images (0: one shared set)
 };
 
 // Where a batch's files go: slot i starts at out + i * slotBytes and receives header i

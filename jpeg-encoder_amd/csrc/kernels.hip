@@ -989,7 +989,7 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
 
     u32 w[32];
     if (active) load_block(coef, b, w);   // in flight while the tables are staged
-    const u32* myTables = tables + image * 1024;
+    const u32* myTables = tables + image * g.tableStride;
     for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = myTables[i];
     __syncthreads();
 

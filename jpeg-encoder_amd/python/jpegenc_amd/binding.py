@@ -21,7 +21,7 @@ EXPORTS = [
     "jpeg_hip_create", "jpeg_hip_destroy", "jpeg_hip_last_error", "jpeg_hip_status_string", "jpeg_hip_stream",
     "jpeg_hip_compute_layout", "jpeg_hip_encode", "jpeg_hip_encode_host", "jpeg_hip_encode_batch", "jpeg_hip_begin", "jpeg_hip_upload_pixels",
     "jpeg_hip_bind_pixels", "jpeg_hip_transform", "jpeg_hip_histograms", "jpeg_hip_histograms_host",
-    "jpeg_hip_huffman_from_histogram", "jpeg_hip_write_dht", "jpeg_hip_write_headers", "jpeg_hip_set_huffman",
+    "jpeg_hip_huffman_from_histogram", "jpeg_hip_standard_huffman", "jpeg_hip_write_dht", "jpeg_hip_write_headers", "jpeg_hip_set_huffman",
     "jpeg_hip_build_huffman", "jpeg_hip_get_huffman", "jpeg_hip_emit_scan", "jpeg_hip_emit_scan_host",
     "jpeg_hip_get_coefficients",
     "jpeg_hip_coefficients_device", "jpeg_hip_analyze_band", "jpeg_hip_finish_band", "jpeg_hip_set_profiling",
@@ -32,7 +32,8 @@ EXPORTS = [
 class Params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("sampling", C.c_int32 * 12),
                 ("qtable", (C.c_float * 64) * 3), ("restart_interval", C.c_int32), ("pad_ones", C.c_int32),
-                ("mcu_row_begin", C.c_int32), ("mcu_row_end", C.c_int32)]
+                ("mcu_row_begin", C.c_int32), ("mcu_row_end", C.c_int32),
+                ("standard_huffman", C.c_int32)]
 
 
 class Layout(C.Structure):
@@ -86,6 +87,7 @@ def lib():
         L.jpeg_hip_histograms.argtypes = [vp, vp]
         L.jpeg_hip_histograms_host.argtypes = [vp, vp]
         L.jpeg_hip_huffman_from_histogram.argtypes = [vp, vp, vp]
+        L.jpeg_hip_standard_huffman.argtypes = [vp, vp]
         L.jpeg_hip_write_dht.argtypes = [vp, vp, i32, i32, vp, i32]
         L.jpeg_hip_write_headers.argtypes = [C.POINTER(Params), vp, vp, vp, i32]
         L.jpeg_hip_set_huffman.argtypes = [vp, vp, vp]
@@ -112,7 +114,8 @@ def _np(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def make_params(width, height, sampling, qtables, restart_interval=0, pad_ones=False, mcu_rows=None):
+def make_params(width, height, sampling, qtables, restart_interval=0, pad_ones=False, mcu_rows=None,
+                standard_huffman=False):
     p = Params()
     p.width, p.height = int(width), int(height)
     s = np.asarray(sampling, np.int32).reshape(12)
@@ -125,7 +128,18 @@ def make_params(width, height, sampling, qtables, restart_interval=0, pad_ones=F
     p.restart_interval = int(restart_interval)
     p.pad_ones = 1 if pad_ones else 0
     p.mcu_row_begin, p.mcu_row_end = (0, 0) if mcu_rows is None else (int(mcu_rows[0]), int(mcu_rows[1]))
+    p.standard_huffman = 1 if standard_huffman else 0
     return p
+
+
+def standard_huffman():
+    """ITU-T T.81 Annex K.3 tables as (lengths uint8[4,256], codes uint16[4,256])."""
+    lengths = np.zeros((4, 256), np.uint8)
+    codes = np.zeros((4, 256), np.uint16)
+    st = lib().jpeg_hip_standard_huffman(_np(lengths), _np(codes))
+    if st != OK:
+        raise JpegHipError(st, "standard tables")
+    return lengths, codes
 
 
 def compute_layout(params):

@@ -369,6 +369,11 @@ struct BlockSymbols {
     std::vector<uint16_t> acBits;      // left-aligned patterns
 };
 
+// Fixed Huffman tables for the next encodes (extension; see encodeImage).
+bool g_fixedTables = false;
+u8 g_fixedLen[4][256];
+uint16_t g_fixedCode[4][256];
+
 struct EncodeResult {
     std::vector<u8> jpeg;
     std::vector<int16_t> coef[3];      // per channel, blocks in MCU order, zig-zag inside a block
@@ -539,7 +544,20 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
         }
     }
     // Extension (sharded images): tables may come from histograms summed over all bands.
-    for (int t = 0; t < 4; ++t) buildHuffman(histOverride ? histOverride + 256 * t : res.hist[t], res.tables[t]);
+    // Extension (fixed tables, e.g. the standard ones of ITU-T T.81 Annex K.3): no table
+    // optimisation at all; a symbol without a code is a caller error.
+    for (int t = 0; t < 4; ++t) {
+        if (g_fixedTables) {
+            HuffTable& ht = res.tables[t];
+            for (int s = 0; s < 256; ++s) {
+                ht.len[s] = g_fixedLen[t][s];
+                ht.code[s] = g_fixedCode[t][s];
+                ht.present[s] = g_fixedLen[t][s] != 0;
+            }
+        } else {
+            buildHuffman(histOverride ? histOverride + 256 * t : res.hist[t], res.tables[t]);
+        }
+    }
 
     // Encoder::serialize, Encoder.cpp:439-488.
     BitSink sink;
@@ -704,6 +722,15 @@ void* orc_encode(const void* rgb, int sampleType, int W, int H, int64_t strideSa
                            histOverride, rstBase, headerH, o->r);
     return o;
 }
+// Tables [DC-Y, DC-C, AC-Y, AC-C] x 256 to use instead of optimised ones; null switches back.
+void orc_set_fixed_tables(const uint8_t* lengths, const uint16_t* codes) {
+    g_fixedTables = lengths != nullptr && codes != nullptr;
+    if (g_fixedTables) {
+        memcpy(g_fixedLen, lengths, sizeof g_fixedLen);
+        memcpy(g_fixedCode, codes, sizeof g_fixedCode);
+    }
+}
+
 void orc_free(void* h) { delete (OrcResult*)h; }
 int64_t orc_jpeg_size(void* h) { return (int64_t)((OrcResult*)h)->r.jpeg.size(); }
 void orc_jpeg_copy(void* h, uint8_t* dst) { const auto& j = ((OrcResult*)h)->r.jpeg; memcpy(dst, j.data(), j.size()); }

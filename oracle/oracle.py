@@ -32,6 +32,8 @@ def lib():
         L.orc_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_free.argtypes = [C.c_void_p]
+        L.orc_set_fixed_tables.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_set_fixed_tables.restype = None
         for name in ("orc_jpeg_size", "orc_scan_offset", "orc_scan_len"):
             getattr(L, name).restype = C.c_int64
             getattr(L, name).argtypes = [C.c_void_p]
@@ -132,6 +134,18 @@ class Encoded:
     @property
     def scan(self):
         return self.jpeg[self.scan_offset:self.scan_offset + self.scan_len]
+
+
+def set_fixed_tables(lengths=None, codes=None):
+    """Use these Huffman tables (uint8/uint16 [4, 256]: DC-Y, DC-C, AC-Y, AC-C) for the following
+    encodes instead of optimised ones; call without arguments to switch back."""
+    L = lib()
+    if lengths is None:
+        L.orc_set_fixed_tables(None, None)
+        return
+    ln = np.ascontiguousarray(lengths, np.uint8).reshape(4, 256)
+    cd = np.ascontiguousarray(codes, np.uint16).reshape(4, 256)
+    L.orc_set_fixed_tables(_p(ln), _p(cd))
 
 
 def encode(rgb, scheme, qtables, restart_interval=0, pad_ones=False, stride=None, hist_override=None, rst_base=0,
