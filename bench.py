@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU and step (batch workload)")
     ap.add_argument("--standard-huffman", action="store_true",
                     help="Annex K tables instead of per-image optimised ones: no histogram pass, no host step")
+    ap.add_argument("--band-of", type=int, default=0,
+                    help="diagnostic: encode only rank 0's band of an image sharded over this many ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -122,7 +124,7 @@ def main():
         lay = B.compute_layout(params)
         y0, y1 = 0, height
     elif sharded:
-        enc = sharding.HipBandEncoder(ctx, B, width, height, scheme, qt, world, rank)
+        enc = sharding.HipBandEncoder(ctx, B, width, height, scheme, qt, args.band_of or world, rank)
         params, lay = enc.params, enc.layout
         y0, y1 = enc.pixel_rows
     else:

@@ -133,12 +133,14 @@ struct HostBuf {
     }
 };
 
+constexpr int kHeaderCapacity = 2048;
+
 struct Pinned {
     float qtab[3 * 192];   // divisors, then the high and low parts of their reciprocals
     uint64_t hist[4 * 256];
-    uint32_t tables[4 * 256];
+    uint32_t tables[4 * 256];           // tables and header travel to the device in one copy
+    uint8_t header[kHeaderCapacity];
     uint64_t result[4];
-    uint8_t header[2048];
 };
 
 }  // namespace
@@ -150,7 +152,7 @@ struct jpeg_hip_ctx {
     jpeg_hip_params prm;
     Geometry geo;
     KGeom kg;
-    bool begun = false, hasPixels = false, transformed = false, hasTables = false;
+    bool begun = false, hasPixels = false, transformed = false, hasTables = false, qtabOnDevice = false;
     int64_t stagedScanLen = -1;   // scan of the current coefficients and tables held in `staging`, or -1
     int64_t streamBits = -1;      // entropy-coded bits the installed tables spend on the histograms they came from, or -1
     const void* rgb = nullptr;
@@ -249,7 +251,7 @@ int ensure_workspace(jpeg_hip_ctx* ctx, int images = 1) {
     HIP_TRY(ctx, ctx->coef.ensure((size_t)nb * 128));
     HIP_TRY(ctx, ctx->qtab.ensure(sizeof ctx->pin->qtab));
     HIP_TRY(ctx, ctx->hist.ensure(1024 * sizeof(uint64_t) * images));
-    HIP_TRY(ctx, ctx->tables.ensure(1024 * sizeof(uint32_t) * images));
+    HIP_TRY(ctx, ctx->tables.ensure(1024 * sizeof(uint32_t) * images + kHeaderCapacity));
     HIP_TRY(ctx, ctx->ivOff.ensure((size_t)(intervals + 1) * 8));
     HIP_TRY(ctx, ctx->ffCount.ensure((size_t)maxChunks * 4));
     HIP_TRY(ctx, ctx->ffOff.ensure((size_t)(maxChunks + 1) * 8));
@@ -286,36 +288,69 @@ int64_t coded_bits(const uint64_t* hist, const uint8_t lengths[4][256]) {
     return bits;
 }
 
-int install_tables(jpeg_hip_ctx* ctx) {
+// Waits for the context's stream.  Polls first: a blocking wait costs tens of microseconds
+// to wake up, which is as long as the kernels of a small image take.
+hipError_t wait_stream(jpeg_hip_ctx* ctx) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q != hipErrorNotReady) return q;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipStreamSynchronize(ctx->stream);
+    }
+}
+
+// Packs the tables for the kernels and sends them, together with headerLen bytes of file
+// header already placed in the pinned block, to the device in one copy.
+int install_tables(jpeg_hip_ctx* ctx, int headerLen = 0) {
     for (int t = 0; t < 4; ++t)
         for (int s = 0; s < 256; ++s)
             ctx->pin->tables[t * 256 + s] = ((uint32_t)ctx->lengths[t][s] << 16) | ctx->codes[t][s];
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->pin->tables, sizeof ctx->pin->tables, hipMemcpyHostToDevice,
-                                ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->pin->tables, sizeof ctx->pin->tables + (size_t)headerLen,
+                                hipMemcpyHostToDevice, ctx->stream));
     ctx->hasTables = true;
     ctx->stagedScanLen = -1;
     ctx->streamBits = -1;
     return JPEG_HIP_OK;
 }
 
-int build_tables(jpeg_hip_ctx* ctx, const uint64_t* hist) {
+// Header bytes for the band (none unless it starts the image) into the pinned block.
+int stage_headers(jpeg_hip_ctx* ctx, int64_t capacity, int* headerLen) {
+    *headerLen = 0;
+    if (!ctx->geo.startsImage) return JPEG_HIP_OK;
+    const int n = write_headers(ctx->prm, ctx->geo, ctx->lengths, ctx->codes, ctx->pin->header, kHeaderCapacity);
+    if (n < 0) return fail(ctx, n, "header assembly failed");
+    if (n > capacity) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "output buffer is too small for the headers");
+    *headerLen = n;
+    return JPEG_HIP_OK;
+}
+
+// Tables from histograms (or the standard ones when hist is null), installed on the device.
+// With stageHeader the band's file header goes along and *headerLen receives its length.
+int build_tables(jpeg_hip_ctx* ctx, const uint64_t* hist, bool stageHeader = false, int64_t capacity = 0,
+                 int* headerLen = nullptr) {
     auto t0 = std::chrono::steady_clock::now();
-    for (int t = 0; t < 4; ++t) {
-        uint64_t total = 0;
-        for (int s = 0; s < 256; ++s) total += hist[t * 256 + s];
-        if (total == 0) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "a symbol histogram is empty");
-        huffman_from_histogram(hist + t * 256, ctx->lengths[t], ctx->codes[t]);
+    if (hist) {
+        for (int t = 0; t < 4; ++t) {
+            uint64_t total = 0;
+            for (int s = 0; s < 256; ++s) total += hist[t * 256 + s];
+            if (total == 0) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "a symbol histogram is empty");
+            huffman_from_histogram(hist + t * 256, ctx->lengths[t], ctx->codes[t]);
+        }
+    } else {
+        standard_huffman(ctx->lengths, ctx->codes);
+    }
+    int hn = 0;
+    if (stageHeader) {
+        const int st = stage_headers(ctx, capacity, &hn);
+        if (st != JPEG_HIP_OK) return st;
+        *headerLen = hn;
     }
     auto t1 = std::chrono::steady_clock::now();
     ctx->times[3] = std::chrono::duration<float, std::milli>(t1 - t0).count();
-    const int st = install_tables(ctx);
-    ctx->streamBits = coded_bits(hist, ctx->lengths);   // hist covers at least this band's symbols
+    const int st = install_tables(ctx, hn);
+    // hist covers at least this band's symbols, so this bounds the band's stream.
+    ctx->streamBits = hist ? coded_bits(hist, ctx->lengths) : -1;
     return st;
-}
-
-int install_standard_tables(jpeg_hip_ctx* ctx) {
-    standard_huffman(ctx->lengths, ctx->codes);
-    return install_tables(ctx);
 }
 
 // Runs the entropy kernels and reads the length back.  prefix: bytes already placed at
@@ -323,6 +358,8 @@ int install_standard_tables(jpeg_hip_ctx* ctx) {
 int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capacity, int writeEoi, int64_t* outLen) {
     mark(ctx, 3);
     ctx->kg.writeEoi = writeEoi;
+    ctx->ws.header = (const uint8_t*)ctx->tables.p + sizeof ctx->pin->tables;
+    ctx->ws.headerLen = (int)prefix;
     // Padding (< 1 byte) and a marker per interval on top of the coded bits, EOI, slack.
     // Without histograms the output capacity bounds the stream: a longer one fails anyway.
     ctx->ws.streamBound = ctx->streamBits < 0 ? capacity - prefix : ctx->streamBits / 8 + 3 * ctx->geo.intervals + 2 + 64;
@@ -331,7 +368,7 @@ int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capac
     mark(ctx, 4);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pin->result, ctx->result.p, sizeof ctx->pin->result, hipMemcpyDeviceToHost,
                                 ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, wait_stream(ctx));
     if (ctx->profiling) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->times[0] = ms;
@@ -367,22 +404,12 @@ int do_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist) {
     return JPEG_HIP_OK;
 }
 
-int fetch_hist_and_build(jpeg_hip_ctx* ctx, const uint64_t* d_hist) {
+// Histograms to the host (not for the standard tables), tables and header to the device.
+int fetch_hist_and_build(jpeg_hip_ctx* ctx, const uint64_t* d_hist, int64_t capacity, int* headerLen) {
+    if (ctx->prm.standard_huffman) return build_tables(ctx, nullptr, true, capacity, headerLen);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pin->hist, d_hist, sizeof ctx->pin->hist, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return build_tables(ctx, ctx->pin->hist);
-}
-
-// Headers (when the band starts the image) go to the front of d_out; returns their length.
-int place_headers(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t capacity, int64_t* prefix) {
-    *prefix = 0;
-    if (!ctx->geo.startsImage) return JPEG_HIP_OK;
-    const int n = write_headers(ctx->prm, ctx->geo, ctx->lengths, ctx->codes, ctx->pin->header, (int)sizeof ctx->pin->header);
-    if (n < 0) return fail(ctx, n, "header assembly failed");
-    if (n > capacity) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "output buffer is too small for the headers");
-    HIP_TRY(ctx, hipMemcpyAsync(d_out, ctx->pin->header, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-    *prefix = n;
-    return JPEG_HIP_OK;
+    HIP_TRY(ctx, wait_stream(ctx));
+    return build_tables(ctx, ctx->pin->hist, true, capacity, headerLen);
 }
 
 }  // namespace
@@ -483,8 +510,10 @@ int jpeg_hip_begin(jpeg_hip_ctx* ctx, const jpeg_hip_params* params) {
     ctx->hasPixels = ctx->transformed = ctx->hasTables = false;
     const int ws = ensure_workspace(ctx);
     if (ws != JPEG_HIP_OK) return ws;
+    // The divisors stay on the device from one image to the next while they do not change.
+    if (ctx->qtabOnDevice && memcmp(ctx->pin->qtab, params->qtable, 192 * sizeof(float)) == 0) return JPEG_HIP_OK;
     // Earlier work on the stream may still read the pinned staging block.
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, wait_stream(ctx));
     for (int i = 0; i < 192; ++i) {
         const float q = params->qtable[i / 64][i % 64];
         const double inv = 1.0 / (double)q;
@@ -494,6 +523,7 @@ int jpeg_hip_begin(jpeg_hip_ctx* ctx, const jpeg_hip_params* params) {
         ctx->pin->qtab[384 + i] = (float)(inv - (double)hi);
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->qtab.p, ctx->pin->qtab, sizeof ctx->pin->qtab, hipMemcpyHostToDevice, ctx->stream));
+    ctx->qtabOnDevice = true;
     return JPEG_HIP_OK;
 }
 
@@ -522,7 +552,7 @@ int jpeg_hip_upload_pixels(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_form
     HIP_TRY(ctx, ctx->pixels.ensure(dstStride * rows));
     HIP_TRY(ctx, hipMemcpy2DAsync(ctx->pixels.p, dstStride, h_rgb, (size_t)stride_bytes, rowBytes, (size_t)rows,
                                   hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, wait_stream(ctx));
     ctx->rgb = ctx->pixels.p;
     ctx->fmt = sample_format;
     ctx->stride = (int64_t)dstStride;
@@ -549,7 +579,7 @@ int jpeg_hip_histograms_host(jpeg_hip_ctx* ctx, uint64_t* h_hist) {
     const int st = do_histograms(ctx, (uint64_t*)ctx->hist.p);
     if (st != JPEG_HIP_OK) return st;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pin->hist, ctx->hist.p, sizeof ctx->pin->hist, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, wait_stream(ctx));
     memcpy(h_hist, ctx->pin->hist, sizeof ctx->pin->hist);
     return JPEG_HIP_OK;
 }
@@ -630,7 +660,7 @@ int jpeg_hip_emit_scan_host(jpeg_hip_ctx* ctx, uint8_t* h_out, int64_t out_capac
     if (!h_out) return JPEG_HIP_OK;
     if (out_capacity < ctx->stagedScanLen) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "host scan buffer too small");
     HIP_TRY(ctx, hipMemcpyAsync(h_out, ctx->staging.p, (size_t)ctx->stagedScanLen, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, wait_stream(ctx));
     return JPEG_HIP_OK;
 }
 
@@ -645,7 +675,7 @@ int jpeg_hip_get_coefficients(jpeg_hip_ctx* ctx, int channel, int16_t* h_out, in
     HIP_TRY(ctx, hipMemcpy2DAsync(h_out, (size_t)perMcu * 128, (const char*)ctx->coef.p + (size_t)g.chanOffset[channel] * 128,
                                   (size_t)g.blocksPerMcu * 128, (size_t)perMcu * 128, (size_t)g.nMcu,
                                   hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, wait_stream(ctx));
     return JPEG_HIP_OK;
 }
 
@@ -676,12 +706,10 @@ int jpeg_hip_finish_band(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t*
     if (!ctx->transformed) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "finish needs analyze");
     if (!ctx->prm.standard_huffman && !d_hist_sum) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int st = ctx->prm.standard_huffman ? install_standard_tables(ctx) : fetch_hist_and_build(ctx, d_hist_sum);
+    int headerLen = 0;
+    const int st = fetch_hist_and_build(ctx, d_hist_sum, out_capacity, &headerLen);
     if (st != JPEG_HIP_OK) return st;
-    int64_t prefix = 0;
-    st = place_headers(ctx, d_out, out_capacity, &prefix);
-    if (st != JPEG_HIP_OK) return st;
-    return run_entropy(ctx, d_out, prefix, out_capacity, ctx->geo.endsImage ? 1 : 0, out_len);
+    return run_entropy(ctx, d_out, headerLen, out_capacity, ctx->geo.endsImage ? 1 : 0, out_len);
 }
 
 int jpeg_hip_encode(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
@@ -717,7 +745,7 @@ int jpeg_hip_encode_host(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format
     if (st != JPEG_HIP_OK) return st;
     if (len > out_capacity) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "host output buffer too small");
     HIP_TRY(ctx, hipMemcpyAsync(h_out, ctx->staging.p, (size_t)len, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, wait_stream(ctx));
     *out_len = len;
     return JPEG_HIP_OK;
 }
@@ -812,7 +840,7 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     HIP_TRY(ctx, launch_histogram(k, (const int16_t*)ctx->coef.p, (unsigned long long*)ctx->hist.p, ctx->stream));
     mark(ctx, 2);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->hostHist.p, ctx->hist.p, (size_t)n * 1024 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, wait_stream(ctx));
 
     auto t0 = std::chrono::steady_clock::now();
     unsigned hw = std::thread::hardware_concurrency();
@@ -858,7 +886,7 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     HIP_TRY(ctx, hipMemcpyAsync(off, ctx->ivOff.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(off + n + 1, ctx->batchFfStart.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(off + 2 * (n + 1), ctx->result.p, 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, wait_stream(ctx));
     if (ctx->profiling) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->times[0] += ms;

@@ -638,12 +638,22 @@ __global__ __launch_bounds__(kEntThreads) void k_histogram(KGeom g, const int16_
         if (lh[i] != 0) atomicAdd(&mine[i], (u64)lh[i]);
 }
 
+// Zeroes n 8-byte words.  A kernel rather than hipMemsetAsync: a launch costs the host a
+// few microseconds, a memset call several times that.
+__global__ __launch_bounds__(256) void k_zero_words(u64* __restrict__ p, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0;
+}
+
 hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(d_hist, 0, sizeof(u64) * 1024 * g.batch, s);
-    if (e != hipSuccess) return e;
-    long long grid = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
+    const long long words = 1024LL * g.batch;
+    hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((words + 255) / 256 > 1024 ? 1024 : (words + 255) / 256)), dim3(256), 0,
+                       s, d_hist, words);
+    // Every workgroup takes the same number of 256-block passes.
+    const long long passes = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
     const long long cap = g.batch > 1 ? (4096 / g.batch > 8 ? 4096 / g.batch : 8) : 2048;
-    if (grid > cap) grid = cap;
+    const long long rounds = (passes + cap - 1) / cap;
+    long long grid = (passes + rounds - 1) / rounds;
+    if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k_histogram, dim3((unsigned)grid, (unsigned)g.batch), dim3(kEntThreads), 0, s, g, d_coef, d_hist);
     return hipGetLastError();
 }
@@ -1339,6 +1349,20 @@ __global__ __launch_bounds__(256) void k_copy_headers(BatchOutput bo) {
     for (u32 i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 
+// Everything the single-pass bit writer and the stuffing pass expect to find cleared, in one
+// launch: the reachable part of the unstuffed stream, the tile states with their counter,
+// the result record.  Also moves the file header from its staging place to the output.
+__global__ __launch_bounds__(256) void k_prepare_entropy(uint4* __restrict__ stream, long long stream16,
+                                                         u64* __restrict__ tileState, long long tileWords,
+                                                         u64* __restrict__ result, const uint8_t* __restrict__ hdr,
+                                                         int hdrLen, uint8_t* __restrict__ out) {
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, step = (long long)gridDim.x * 256;
+    for (long long i = tid; i < stream16; i += step) stream[i] = make_uint4(0, 0, 0, 0);
+    for (long long i = tid; i < tileWords; i += step) tileState[i] = 0;
+    if (tid < 4) result[tid] = 0;
+    for (long long i = tid; i < hdrLen; i += step) out[i] = hdr[i];
+}
+
 static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const u32* d_tables,
                                     const EntropyWorkspace& ws, uint8_t* d_out, long long prefixLen,
                                     long long outCapacity, const BatchOutput* bo, hipStream_t s) {
@@ -1348,12 +1372,10 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     // The bit writer ORs into the stream, so the part it can reach starts out as zeros.
     long long zero = ws.streamBound < 0 ? ws.unstuffedCap : (ws.streamBound + kStuffChunk + 63) / 16 * 16;
     if (zero > ws.unstuffedCap) zero = ws.unstuffedCap;
-    e = hipMemsetAsync(ws.unstuffed, 0, (size_t)zero, s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(ws.tileState, 0, (size_t)(tileCount + 1) * 8, s);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(ws.result, 0, 4 * 8, s);
-    if (e != hipSuccess) return e;
+    long long prepGrid = zero / 16 / (256 * 4);
+    prepGrid = prepGrid < 1 ? 1 : (prepGrid > 2048 ? 2048 : prepGrid);
+    hipLaunchKernelGGL(k_prepare_entropy, dim3((unsigned)prepGrid), dim3(256), 0, s, (uint4*)ws.unstuffed, zero / 16,
+                       ws.tileState, tileCount + 1, ws.result, ws.header, bo ? 0 : ws.headerLen, d_out);
     hipLaunchKernelGGL(k_encode_bits, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.tileState,
                        ws.ivOff, ws.result, (u32*)ws.unstuffed);
     long long chunkGrid = ws.maxChunks < 2048 ? ws.maxChunks : 2048;
