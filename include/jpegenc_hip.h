@@ -235,6 +235,39 @@ int jpeg_hip_finish_band(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t*
 int jpeg_hip_set_profiling(jpeg_hip_ctx* ctx, int enabled);
 int jpeg_hip_get_timings(jpeg_hip_ctx* ctx, float out_ms[4]);
 
+/* ---- verification decoder ---------------------------------------------------------------- */
+
+/* The way back, for checking files on the box that made them: baseline Huffman decoding
+ * (restart intervals included) on the host, then on the GPU dequantization, the inverse
+ * transform of DCT::directIDCT (DCT.cpp:46-79), sample replication for subsampled chroma,
+ * the matrix of convertYCbCrToRGBAVXImpl (SIMD256.h:188-216; Encoder::convertToRGB,
+ * Encoder.cpp:25-33) and the byte rounding of ImageLoader::SavePPM (ImageLoader.cpp:168-172).
+ * Accepts 8-bit, three-component, single-scan baseline files with integer sampling ratios --
+ * everything this encoder writes.  A checker, not a fast path. */
+typedef struct jpeg_hip_image_info {
+    int32_t width, height;
+    int32_t h_samp[3], v_samp[3];   /* sampling factors of the frame header */
+    int32_t restart_interval;       /* MCUs, 0 = none */
+    int64_t total_blocks;
+} jpeg_hip_image_info;
+
+/* Header parse only.  Pure host function. */
+int jpeg_hip_decode_info(const uint8_t* h_jpeg, int64_t len, jpeg_hip_image_info* info);
+/* File in host memory -> interleaved RGB8 in device memory (row stride in bytes). */
+int jpeg_hip_decode(jpeg_hip_ctx* ctx, const uint8_t* h_jpeg, int64_t len, uint8_t* d_rgb, int64_t stride_bytes,
+                    int64_t capacity_bytes, jpeg_hip_image_info* info);
+/* Same, RGB8 copied to the host. */
+int jpeg_hip_decode_host(jpeg_hip_ctx* ctx, const uint8_t* h_jpeg, int64_t len, uint8_t* h_rgb, int64_t stride_bytes,
+                         int64_t capacity_bytes, jpeg_hip_image_info* info);
+/* Quantized coefficients of the last decoded file: blocks in scan order, 64 zig-zag ordered
+ * values each -- the layout of jpeg_hip_coefficients_device, so a file can be compared with
+ * the coefficients it was written from. */
+int jpeg_hip_decoded_coefficients(jpeg_hip_ctx* ctx, int16_t* h_out, int64_t capacity_values);
+/* Mean squared error and PSNR (dB, 8-bit peak; +inf for identical images) between two
+ * RGB8 images in device memory. */
+int jpeg_hip_psnr(jpeg_hip_ctx* ctx, const uint8_t* d_a, int64_t stride_a, const uint8_t* d_b, int64_t stride_b,
+                  int32_t width, int32_t height, double* mse, double* psnr);
+
 #ifdef __cplusplus
 }
 #endif

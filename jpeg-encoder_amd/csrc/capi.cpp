@@ -10,6 +10,7 @@
 #include <thread>
 #include <vector>
 
+#include "decode.h"
 #include "internal.h"
 #include "kernels.h"
 
@@ -159,7 +160,8 @@ struct jpeg_hip_ctx {
     int fmt = JPEG_HIP_RGB8;
     int64_t stride = 0;
     DevBuf pixels, coef, qtab, hist, tables, ivOff, ffCount, ffOff, scanTmp, result, unstuffed,
-        staging, batchHdr, batchHdrLen, batchFfStart, tileState;
+        staging, batchHdr, batchHdrLen, batchFfStart, tileState, decCoef, decPlanes, decTables, decRgb, decSum;
+    jpeghip::DecodedStream* decoded = nullptr;   // last file given to the verification decoder
     HostBuf hostHist, hostTables, hostHdr, hostHdrLen, hostOffsets;
     EntropyWorkspace ws;
     Pinned* pin = nullptr;
@@ -458,7 +460,8 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->ffOff, &ctx->scanTmp, &ctx->result,
                       &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart,
-                      &ctx->tileState};
+                      &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum};
+    delete ctx->decoded;
     for (DevBuf* b : bufs) b->release();
     HostBuf* hbufs[] = {&ctx->hostHist, &ctx->hostTables, &ctx->hostHdr, &ctx->hostHdrLen, &ctx->hostOffsets};
     for (HostBuf* b : hbufs) b->release();
@@ -951,3 +954,140 @@ extern "C" int jpeg_hip_encode_batch(jpeg_hip_ctx* ctx, const void* d_rgb, int s
     ctx->stagedScanLen = -1;
     return JPEG_HIP_OK;
 }
+
+// ---- verification decoder ------------------------------------------------------------------
+namespace {
+
+void fill_info(const DecodedStream& d, jpeg_hip_image_info* info) {
+    info->width = d.width;
+    info->height = d.height;
+    for (int c = 0; c < 3; ++c) {
+        info->h_samp[c] = d.hSamp[c];
+        info->v_samp[c] = d.vSamp[c];
+    }
+    info->restart_interval = d.restartInterval;
+    info->total_blocks = d.totalBlocks;
+}
+
+// Decodes the file's entropy-coded data on the host and runs the inverse kernels; the
+// RGB8 image goes to d_rgb.
+int decode_to_device(jpeg_hip_ctx* ctx, const uint8_t* h_jpeg, int64_t len, uint8_t* d_rgb, int64_t stride,
+                     int64_t capacity, jpeg_hip_image_info* info) {
+    if (!ctx->decoded) ctx->decoded = new (std::nothrow) DecodedStream();
+    if (!ctx->decoded) return fail(ctx, JPEG_HIP_ERR_HIP, "out of host memory");
+    DecodedStream& d = *ctx->decoded;
+    std::string err;
+    int st = decode_entropy(h_jpeg, len, d, err);
+    if (st != JPEG_HIP_OK) {
+        d.coef.clear();
+        return fail(ctx, st, err);
+    }
+    if (info) fill_info(d, info);
+    if (stride < (int64_t)d.width * 3 || capacity < stride * (int64_t)(d.height - 1) + (int64_t)d.width * 3)
+        return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "RGB buffer too small for the decoded image");
+    DGeom g;
+    g.width = d.width;
+    g.height = d.height;
+    g.mcusPerRow = d.mcusPerRow;
+    g.mcuRows = d.mcuRows;
+    g.bpm = d.blocksPerMcu;
+    g.off1 = d.chanOffset[1];
+    g.off2 = d.chanOffset[2];
+    g.totalBlocks = d.totalBlocks;
+    long long offset = 0;
+    for (int c = 0; c < 3; ++c) {
+        g.hS[c] = d.hSamp[c];
+        g.vS[c] = d.vSamp[c];
+        g.wf[c] = d.mcuW / 8 / d.hSamp[c];
+        g.hf[c] = d.mcuH / 8 / d.vSamp[c];
+        g.planeW[c] = d.mcusPerRow * d.hSamp[c] * 8;
+        g.planeH[c] = d.mcuRows * d.vSamp[c] * 8;
+        g.planeOffset[c] = offset;
+        offset += (long long)g.planeW[c] * g.planeH[c];
+    }
+    // Divisors per component in zig-zag order, then the cosine table of DCT::directIDCT.
+    float tables[192 + 64];
+    for (int c = 0; c < 3; ++c)
+        for (int z = 0; z < 64; ++z) tables[c * 64 + z] = (float)d.qtables[d.tq[c]][z];
+    for (int x = 0; x < 8; ++x)
+        for (int i = 0; i < 8; ++i) tables[192 + x * 8 + i] = (float)std::cos(3.14159265358979323846 * (2 * x + 1) * i / 16.0);
+    HIP_TRY(ctx, ctx->decCoef.ensure(d.coef.size() * sizeof(int16_t)));
+    HIP_TRY(ctx, ctx->decPlanes.ensure((size_t)offset * sizeof(float)));
+    HIP_TRY(ctx, ctx->decTables.ensure(sizeof tables));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->decCoef.p, d.coef.data(), d.coef.size() * sizeof(int16_t), hipMemcpyHostToDevice,
+                                ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->decTables.p, tables, sizeof tables, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, launch_inverse_blocks(g, (const int16_t*)ctx->decCoef.p, (const float*)ctx->decTables.p,
+                                       (const float*)ctx->decTables.p + 192, (float*)ctx->decPlanes.p, ctx->stream));
+    HIP_TRY(ctx, launch_planes_to_rgb(g, (const float*)ctx->decPlanes.p, d_rgb, stride, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // `tables` and d.coef are pageable host memory
+    return JPEG_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jpeg_hip_decode_info(const uint8_t* h_jpeg, int64_t len, jpeg_hip_image_info* info) {
+    if (!h_jpeg || !info) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    DecodedStream d;
+    std::string err;
+    const int st = parse_headers(h_jpeg, len, d, err);
+    if (st != JPEG_HIP_OK) return st;
+    fill_info(d, info);
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_decode(jpeg_hip_ctx* ctx, const uint8_t* h_jpeg, int64_t len, uint8_t* d_rgb, int64_t stride_bytes,
+                    int64_t capacity_bytes, jpeg_hip_image_info* info) {
+    if (!ctx || !h_jpeg || !d_rgb) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return decode_to_device(ctx, h_jpeg, len, d_rgb, stride_bytes, capacity_bytes, info);
+}
+
+int jpeg_hip_decode_host(jpeg_hip_ctx* ctx, const uint8_t* h_jpeg, int64_t len, uint8_t* h_rgb, int64_t stride_bytes,
+                         int64_t capacity_bytes, jpeg_hip_image_info* info) {
+    if (!ctx || !h_jpeg || !h_rgb) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    jpeg_hip_image_info local;
+    int st = jpeg_hip_decode_info(h_jpeg, len, &local);
+    if (st != JPEG_HIP_OK) return fail(ctx, st, "unsupported or damaged JPEG headers");
+    if (stride_bytes < (int64_t)local.width * 3 ||
+        capacity_bytes < stride_bytes * (int64_t)(local.height - 1) + (int64_t)local.width * 3)
+        return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "RGB buffer too small for the decoded image");
+    const int64_t tight = (int64_t)local.width * 3;
+    HIP_TRY(ctx, ctx->decRgb.ensure((size_t)(tight * local.height)));
+    st = decode_to_device(ctx, h_jpeg, len, (uint8_t*)ctx->decRgb.p, tight, tight * local.height, info);
+    if (st != JPEG_HIP_OK) return st;
+    HIP_TRY(ctx, hipMemcpy2DAsync(h_rgb, (size_t)stride_bytes, ctx->decRgb.p, (size_t)tight, (size_t)tight,
+                                  (size_t)local.height, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_decoded_coefficients(jpeg_hip_ctx* ctx, int16_t* h_out, int64_t capacity_values) {
+    if (!ctx || !h_out) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->decoded || ctx->decoded->coef.empty()) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "nothing decoded yet");
+    if (capacity_values < (int64_t)ctx->decoded->coef.size())
+        return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "coefficient buffer too small");
+    memcpy(h_out, ctx->decoded->coef.data(), ctx->decoded->coef.size() * sizeof(int16_t));
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_psnr(jpeg_hip_ctx* ctx, const uint8_t* d_a, int64_t stride_a, const uint8_t* d_b, int64_t stride_b,
+                  int32_t width, int32_t height, double* mse, double* psnr) {
+    if (!ctx || !d_a || !d_b || width < 1 || height < 1 || stride_a < (int64_t)width * 3 || stride_b < (int64_t)width * 3)
+        return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, ctx->decSum.ensure(8));
+    HIP_TRY(ctx, launch_squared_error(d_a, stride_a, d_b, stride_b, width, height, (unsigned long long*)ctx->decSum.p,
+                                      ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin->result, ctx->decSum.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, wait_stream(ctx));
+    const double m = (double)ctx->pin->result[0] / ((double)width * height * 3.0);
+    if (mse) *mse = m;
+    if (psnr) *psnr = m == 0.0 ? INFINITY : 10.0 * std::log10(255.0 * 255.0 / m);
+    return JPEG_HIP_OK;
+}
+
+}  // extern "C"

@@ -25,7 +25,8 @@ EXPORTS = [
     "jpeg_hip_build_huffman", "jpeg_hip_get_huffman", "jpeg_hip_emit_scan", "jpeg_hip_emit_scan_host",
     "jpeg_hip_get_coefficients",
     "jpeg_hip_coefficients_device", "jpeg_hip_analyze_band", "jpeg_hip_finish_band", "jpeg_hip_set_profiling",
-    "jpeg_hip_get_timings",
+    "jpeg_hip_get_timings", "jpeg_hip_decode_info", "jpeg_hip_decode", "jpeg_hip_decode_host",
+    "jpeg_hip_decoded_coefficients", "jpeg_hip_psnr",
 ]
 
 
@@ -42,6 +43,11 @@ class Layout(C.Structure):
                 ("band_mcu_rows", C.c_int32), ("h_factor", C.c_int32 * 3), ("v_factor", C.c_int32 * 3),
                 ("blocks_per_mcu", C.c_int32), ("blocks", C.c_int64 * 3), ("total_blocks", C.c_int64),
                 ("intervals", C.c_int64), ("max_jpeg_bytes", C.c_int64)]
+
+
+class ImageInfo(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("h_samp", C.c_int32 * 3), ("v_samp", C.c_int32 * 3),
+                ("restart_interval", C.c_int32), ("total_blocks", C.c_int64)]
 
 
 class JpegHipError(RuntimeError):
@@ -81,6 +87,11 @@ def lib():
         L.jpeg_hip_encode_host.argtypes = [vp, vp, i32, i64, C.POINTER(Params), vp, i64, C.POINTER(i64)]
         L.jpeg_hip_encode_batch.argtypes = [vp, vp, i32, i64, i64, i32, C.POINTER(Params), vp, i64, vp]
         L.jpeg_hip_begin.argtypes = [vp, C.POINTER(Params)]
+        L.jpeg_hip_decode_info.argtypes = [vp, i64, C.POINTER(ImageInfo)]
+        L.jpeg_hip_decode.argtypes = [vp, vp, i64, vp, i64, i64, C.POINTER(ImageInfo)]
+        L.jpeg_hip_decode_host.argtypes = [vp, vp, i64, vp, i64, i64, C.POINTER(ImageInfo)]
+        L.jpeg_hip_decoded_coefficients.argtypes = [vp, vp, i64]
+        L.jpeg_hip_psnr.argtypes = [vp, vp, i64, vp, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.jpeg_hip_upload_pixels.argtypes = [vp, vp, i32, i64]
         L.jpeg_hip_bind_pixels.argtypes = [vp, vp, i32, i64]
         L.jpeg_hip_transform.argtypes = [vp, i32]
@@ -140,6 +151,16 @@ def standard_huffman():
     if st != OK:
         raise JpegHipError(st, "standard tables")
     return lengths, codes
+
+
+def decode_info(jpeg):
+    """Frame parameters of a baseline JPEG (bytes) without decoding it."""
+    buf = np.frombuffer(jpeg, np.uint8)
+    info = ImageInfo()
+    st = lib().jpeg_hip_decode_info(_np(buf), buf.size, C.byref(info))
+    if st != OK:
+        raise JpegHipError(st, "unsupported or damaged JPEG headers")
+    return info
 
 
 def compute_layout(params):
@@ -309,6 +330,36 @@ class Context:
 
     def set_profiling(self, enabled):
         self._check(lib().jpeg_hip_set_profiling(self._h, 1 if enabled else 0))
+
+    # ---- verification decoder ----
+    def decode_host(self, jpeg):
+        """bytes -> (uint8 [H, W, 3], ImageInfo)."""
+        buf = np.frombuffer(jpeg, np.uint8)
+        info = decode_info(jpeg)
+        out = np.zeros((info.height, info.width, 3), np.uint8)
+        self._check(lib().jpeg_hip_decode_host(self._h, _np(buf), buf.size, _np(out), info.width * 3, out.size,
+                                               C.byref(info)))
+        return out, info
+
+    def decode(self, jpeg, d_rgb, stride, capacity):
+        """bytes -> RGB8 at device pointer d_rgb; returns ImageInfo."""
+        buf = np.frombuffer(jpeg, np.uint8)
+        info = ImageInfo()
+        self._check(lib().jpeg_hip_decode(self._h, _np(buf), buf.size, C.c_void_p(d_rgb), stride, capacity,
+                                          C.byref(info)))
+        return info
+
+    def decoded_coefficients(self, info):
+        out = np.zeros((int(info.total_blocks), 64), np.int16)
+        self._check(lib().jpeg_hip_decoded_coefficients(self._h, _np(out), out.size))
+        return out
+
+    def psnr(self, d_a, stride_a, d_b, stride_b, width, height):
+        """(mse, psnr in dB) between two RGB8 images in device memory."""
+        mse, psnr = C.c_double(0), C.c_double(0)
+        self._check(lib().jpeg_hip_psnr(self._h, C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, width, height,
+                                        C.byref(mse), C.byref(psnr)))
+        return mse.value, psnr.value
 
     def timings(self):
         t = np.zeros(4, np.float32)
