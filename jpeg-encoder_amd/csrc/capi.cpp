@@ -273,6 +273,7 @@ int ensure_workspace(jpeg_hip_ctx* ctx, int images = 1) {
     ws.maxChunks = maxChunks;
     ws.tileState = (unsigned long long*)ctx->tileState.p;
     ws.streamBound = -1;
+    ws.avgBlockBits = -1;
     return JPEG_HIP_OK;
 }
 
@@ -360,6 +361,8 @@ int build_tables(jpeg_hip_ctx* ctx, const uint64_t* hist, bool stageHeader = fal
 int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capacity, int writeEoi, int64_t* outLen) {
     mark(ctx, 3);
     ctx->kg.writeEoi = writeEoi;
+    // The histograms (and so streamBits) cover the whole image even when this context encodes a band.
+    ctx->ws.avgBlockBits = ctx->streamBits < 0 ? -1 : ctx->streamBits / ((int64_t)ctx->geo.mcuRows * ctx->geo.mcusPerRow * ctx->geo.blocksPerMcu);
     ctx->ws.header = (const uint8_t*)ctx->tables.p + sizeof ctx->pin->tables;
     ctx->ws.headerLen = (int)prefix;
     // Padding (< 1 byte) and a marker per interval on top of the coded bits, EOI, slack.
@@ -882,6 +885,7 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     bo.ffStart = (unsigned long long*)ctx->batchFfStart.p;
     // Without histograms the slots bound the stream: a longer one fails anyway.
     ctx->ws.streamBound = totalBits < 0 ? (int64_t)n * slotBytes : totalBits / 8 + 3 * (int64_t)n + 2 + 64;
+    ctx->ws.avgBlockBits = totalBits < 0 ? -1 : totalBits / ((int64_t)n * g.totalBlocks);
     mark(ctx, 3);
     HIP_TRY(ctx, launch_entropy_batch(k, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, bo, ctx->stream));
     mark(ctx, 4);

@@ -61,6 +61,7 @@ struct EntropyWorkspace {
     long long maxChunks;
     unsigned long long* tileState;   // [tiles + 1] of the single-pass bit writer (tiles of 256 blocks)
     long long streamBound;           // upper bound of the unstuffed stream in bytes, or < 0 when unknown
+    long long avgBlockBits;          // mean entropy-coded bits per block according to the histograms, or < 0 when unknown
     const uint8_t* header;           // file header staged in device memory, copied to the front of the output
     int headerLen;                   // (0: none); prefixLen of launch_entropy covers it
 };

@@ -835,30 +835,90 @@ __device__ __forceinline__ bool interval_has_eoi(const KGeom& g, long long k) {
 
 // ---- bit writer ------------------------------------------------------------------------
 // One thread per block appends its codes MSB first.  A workgroup's 256 blocks cover one
-// contiguous bit range; it is assembled in LDS (ds_or for the words two blocks share) and
-// copied out with coalesced stores, only the range's first and last word being merged
-// into the zeroed buffer with atomicOr.  Ranges too long for the LDS stage are written
-// straight to memory by the same code.  Words are byte swapped so that memory holds the
-// big-endian bit string BitBuffer::pushBits builds (BitBuffer.cpp:128-204).
-constexpr int kEmitStageWords = 4096;
+// contiguous bit range; it is assembled in LDS (native word order, ds_or for the words two
+// blocks share) and copied out byte swapped with coalesced stores, so that memory holds the
+// big-endian bit string BitBuffer::pushBits builds (BitBuffer.cpp:128-204).  Only the
+// range's first and last word are merged into the zeroed buffer with atomicOr.  Ranges too
+// long for the LDS stage are written straight to memory.
+constexpr int kEmitStageShort = 2048;   // stage words of a tile of short blocks (8 bytes per block on average)
+constexpr int kEmitStageLong = 6144;    // ... of long blocks (up to 96 bytes per block on average)
 
+// Where a lane's bits go: the LDS stage (native order) or the global stream (swapped).
+struct BitTarget {
+    u32* words;
+    long long bias;   // index of the stream word that words[0] stands for
+    bool swap;
+    __device__ __forceinline__ void or_word(long long index, u32 v) const {
+        if (v != 0) atomicOr(&words[index - bias], swap ? __builtin_bswap32(v) : v);
+    }
+    // ORs up to 32 bits, given left aligned in v, into the stream at bit position pos.
+    __device__ __forceinline__ void or32(u64 pos, u32 v) const {
+        const long long d = (long long)(pos >> 5);
+        const int sh = (int)(pos & 31);
+        or_word(d, v >> sh);
+        if (sh != 0) or_word(d + 1, v << (32 - sh));
+    }
+};
+
+// First walk: the block's bit string, starting at bit 0, into a few words of LDS private to
+// the lane, and its length.  A block longer than the private words is only measured.
+constexpr int kPrivWords = 8;
+constexpr int kPrivPitch = 9;   // odd, so that the lanes' words spread over the banks
+
+struct PrivateVisitor {
+    const u32* dcTab;
+    const u32* acTab;
+    u32* words;
+    u64 acc;    // pending bits, right aligned
+    int n;      // number of pending bits (< 32 between calls)
+    int word;   // words completed
+    __device__ __forceinline__ void put(u32 bits, int len) {
+        acc = (acc << len) | bits;
+        n += len;
+        if (n >= 32) {
+            if (word < kPrivWords) words[word] = (u32)(acc >> (n - 32));
+            ++word;
+            n -= 32;
+        }
+    }
+    __device__ __forceinline__ void dc(int cat, u32 amp) {
+        const u32 e = dcTab[cat];
+        put(((e & 0xffffu) << cat) | amp, (int)(e >> 16) + cat);
+    }
+    __device__ __forceinline__ void ac(int sym, int cat, u32 amp) {
+        const u32 e = acTab[sym];
+        put(((e & 0xffffu) << cat) | amp, (int)(e >> 16) + cat);
+    }
+    __device__ __forceinline__ void zrl(int cnt) {
+        const u32 e = acTab[0xF0];
+        for (int i = 0; i < cnt; ++i) put(e & 0xffffu, (int)(e >> 16));
+    }
+    __device__ __forceinline__ void eob() {
+        const u32 e = acTab[0];
+        put(e & 0xffffu, (int)(e >> 16));
+    }
+    __device__ __forceinline__ u32 finish() {   // returns the length in bits
+        if (n > 0 && word < kPrivWords) words[word] = (u32)(acc << (32 - n));
+        return (u32)(word * 32 + n);
+    }
+};
+
+// Second walk, for the blocks that did not fit their private words: straight to the target.
 struct EmitVisitor {
     const u32* dcTab;
     const u32* acTab;
-    u32* words;       // LDS stage or the global buffer, indexed by (word - bias)
-    long long bias;
+    BitTarget out;
     long long word;   // index of the word being filled
     u64 acc;          // pending bits, right aligned
     int n;            // number of pending bits (< 32 between calls)
     bool first;
     __device__ __forceinline__ void flush_word() {
         const u32 w = (u32)(acc >> (n - 32));
-        const u32 be = __builtin_bswap32(w);
         if (first) {
-            atomicOr(&words[word - bias], be);
+            out.or_word(word, w);
             first = false;
         } else {
-            words[word - bias] = be;
+            out.words[word - out.bias] = out.swap ? __builtin_bswap32(w) : w;
         }
         ++word;
         n -= 32;
@@ -886,10 +946,7 @@ struct EmitVisitor {
         put(e & 0xffffu, (int)(e >> 16));
     }
     __device__ __forceinline__ void finish() {
-        if (n > 0) {
-            const u32 w = (u32)(acc << (32 - n));
-            atomicOr(&words[word - bias], __builtin_bswap32(w));
-        }
+        if (n > 0) out.or_word(word, (u32)(acc << (32 - n)));
     }
 };
 
@@ -974,14 +1031,20 @@ __device__ __forceinline__ bool look_back(const u64* state, long long tile, u64 
     }
 }
 
+// kPrivate: blocks are short on average (photographic content), so the first walk keeps
+// each block's bits in a few private LDS words and the second walk is a copy; otherwise the
+// first walk only measures and every block is walked twice.
+template <bool kPrivate>
 __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int16_t* __restrict__ coef,
                                                              const u32* __restrict__ tables, u64* __restrict__ state,
                                                              u64* __restrict__ ivOff, u64* __restrict__ result,
                                                              u32* __restrict__ words) {
     __shared__ u32 tab[4 * 256];
-    __shared__ u32 stage[kEmitStageWords];
+    constexpr int kStageWords = kPrivate ? kEmitStageShort : kEmitStageLong;
+    __shared__ u32 stage[kStageWords];
     __shared__ u64 span[2];
     __shared__ PosSummary waveSum[kEntThreads / 64];
+    __shared__ u32 priv[kPrivate ? kEntThreads * kPrivPitch : 1];
     __shared__ u64 tileStart;
     __shared__ long long tileNo;
     const long long tilesPerImage = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
@@ -1020,9 +1083,15 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
         firstOfInterval = b == ivFirstBlock;
         lastOfInterval = b == ivEnd - 1;
         const int t = c == 0 ? 0 : 1;
-        LengthVisitor len{tab + 256 * t, tab + 512 + 256 * t, 0u};
-        walk_block(w, pred, len);
-        bits = len.bits;
+        if (kPrivate) {
+            PrivateVisitor pv{tab + 256 * t, tab + 512 + 256 * t, priv + threadIdx.x * kPrivPitch, 0, 0, 0};
+            walk_block(w, pred, pv);
+            bits = pv.finish();
+        } else {
+            LengthVisitor len{tab + 256 * t, tab + 512 + 256 * t, 0u};
+            walk_block(w, pred, len);
+            bits = len.bits;
+        }
         mine.x = bits;
         if (lastOfInterval) {
             mine.x |= 0x80000000u;
@@ -1110,25 +1179,33 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
     __syncthreads();
     const u64 wordBase = span[0] >> 5;
     const u64 nWords = ((span[1] + 31) >> 5) - wordBase;
-    const bool staged = nWords <= (u64)kEmitStageWords;
+    const bool staged = nWords <= (u64)kStageWords;
     if (staged) {
         for (u32 i = threadIdx.x; i < (u32)nWords; i += kEntThreads) stage[i] = 0;
         __syncthreads();
     }
     if (active) {
-        const int t = c == 0 ? 0 : 1;
-        EmitVisitor vis{tab + 256 * t,       tab + 512 + 256 * t, staged ? stage : words, staged ? (long long)wordBase : 0,
-                        (long long)(pos >> 5), 0,                  (int)(pos & 31),        true};
-        if (leadMarker) vis.put(leadMarker, 16);
-        walk_block(w, pred, vis);
-        if (padBits != 0) vis.put(g.padOnes ? (1u << padBits) - 1u : 0u, padBits);
-        if (tailEoi) vis.put(0xffd9u, 16);
-        vis.finish();
+        const BitTarget out{staged ? stage : words, staged ? (long long)wordBase : 0, !staged};
+        const u64 start = pos + (leadMarker ? 16 : 0);   // first bit of the block itself
+        if (leadMarker) out.or32(pos, leadMarker << 16);
+        if (kPrivate && bits <= (u32)(kPrivWords * 32)) {
+            const u32* mine32 = priv + threadIdx.x * kPrivPitch;
+#pragma unroll
+            for (int k = 0; k < kPrivWords; ++k)
+                if ((u32)(32 * k) < bits) out.or32(start + 32 * k, mine32[k]);
+        } else {
+            const int t = c == 0 ? 0 : 1;
+            EmitVisitor vis{tab + 256 * t, tab + 512 + 256 * t, out, (long long)(start >> 5), 0, (int)(start & 31), true};
+            walk_block(w, pred, vis);
+            vis.finish();
+        }
+        if (padBits != 0 && g.padOnes) out.or32(start + bits, ((1u << padBits) - 1u) << (32 - padBits));
+        if (tailEoi) out.or32(start + bits + padBits, 0xffd9u << 16);
     }
     if (staged) {
         __syncthreads();
         for (u32 i = threadIdx.x; i < (u32)nWords; i += kEntThreads) {
-            const u32 v = stage[i];
+            const u32 v = __builtin_bswap32(stage[i]);
             if (i == 0 || i == (u32)nWords - 1) {
                 if (v != 0) atomicOr(&words[wordBase + i], v);
             } else {
@@ -1376,8 +1453,14 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     prepGrid = prepGrid < 1 ? 1 : (prepGrid > 2048 ? 2048 : prepGrid);
     hipLaunchKernelGGL(k_prepare_entropy, dim3((unsigned)prepGrid), dim3(256), 0, s, (uint4*)ws.unstuffed, zero / 16,
                        ws.tileState, tileCount + 1, ws.result, ws.header, bo ? 0 : ws.headerLen, d_out);
-    hipLaunchKernelGGL(k_encode_bits, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.tileState,
-                       ws.ivOff, ws.result, (u32*)ws.unstuffed);
+    // Long blocks (noise, q=100) do not fit the private words; unknown lengths count as short.
+    const bool shortBlocks = ws.avgBlockBits <= 128;
+    if (shortBlocks)
+        hipLaunchKernelGGL(k_encode_bits<true>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
+                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed);
+    else
+        hipLaunchKernelGGL(k_encode_bits<false>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
+                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed);
     long long chunkGrid = ws.maxChunks < 2048 ? ws.maxChunks : 2048;
     if (chunkGrid < 1) chunkGrid = 1;
     hipLaunchKernelGGL(k_count_ff, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.result,
