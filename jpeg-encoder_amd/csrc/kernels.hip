@@ -32,23 +32,33 @@ __device__ constexpr int kZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 
 #define AAN_S6 0x1.4e7ae8p-1f
 #define AAN_S7 0x1.480da4p+0f
 
-// One 8-point AAN pass, operation order of SIMD256.h:354-415.
-__device__ __forceinline__ void aan1d(float& x0, float& x1, float& x2, float& x3, float& x4, float& x5, float& x6,
-                                      float& x7) {
-    const float t0 = x0 + x7, t1 = x1 + x6, t2 = x2 + x5, t3 = x3 + x4;
-    const float t4 = x3 - x4, t5 = x2 - x5, t6 = x1 - x6, t7 = x0 - x7;
-    const float r0 = t0 + t3, r1 = t1 + t2, r2 = t1 - t2, r3 = t0 - t3;
-    const float r4 = t4 + t5, r5 = t5 + t6, r6 = t6 + t7, r7 = t7;
-    const float u0 = r0 + r1, u1 = r0 - r1;
-    float u2 = r2 + r3;
-    const float z = r6 - r4;
+// Two floats that travel through the same instructions (v_pk_add_f32, v_pk_mul_f32,
+// v_pk_fma_f32: two IEEE single operations per lane and instruction, each rounded like its
+// scalar counterpart).  The transform kernels issue VALU instructions back to back, so
+// halving their number is what makes them faster.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 splat(float x) { return (f2){x, x}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// One 8-point AAN pass, operation order of SIMD256.h:354-415.  T: float, or f2 for two
+// independent passes at once.
+template <class T>
+__device__ __forceinline__ void aan1d(T& x0, T& x1, T& x2, T& x3, T& x4, T& x5, T& x6, T& x7) {
+    const T t0 = x0 + x7, t1 = x1 + x6, t2 = x2 + x5, t3 = x3 + x4;
+    const T t4 = x3 - x4, t5 = x2 - x5, t6 = x1 - x6, t7 = x0 - x7;
+    const T r0 = t0 + t3, r1 = t1 + t2, r2 = t1 - t2, r3 = t0 - t3;
+    const T r4 = t4 + t5, r5 = t5 + t6, r6 = t6 + t7, r7 = t7;
+    const T u0 = r0 + r1, u1 = r0 - r1;
+    T u2 = r2 + r3;
+    const T z = r6 - r4;
     u2 = u2 * AAN_A1;
-    const float za5 = z * AAN_A5;
-    const float u4 = (r4 * AAN_A2) - za5;
-    const float u5m = r5 * AAN_A1;
-    const float u6 = (r6 * AAN_A4) - za5;
-    const float y2 = u2 + r3, y6 = r3 - u2;
-    const float u5 = u5m + r7, u7 = r7 - u5m;
+    const T za5 = z * AAN_A5;
+    const T u4 = (r4 * AAN_A2) - za5;
+    const T u5m = r5 * AAN_A1;
+    const T u6 = (r6 * AAN_A4) - za5;
+    const T y2 = u2 + r3, y6 = r3 - u2;
+    const T u5 = u5m + r7, u7 = r7 - u5m;
     x0 = u0 * AAN_S0;
     x4 = u1 * AAN_S4;
     x2 = y2 * AAN_S2;
@@ -67,6 +77,29 @@ __device__ __forceinline__ void aan2d(float (&v)[64]) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) aan1d(v[c], v[8 + c], v[16 + c], v[24 + c], v[32 + c], v[40 + c], v[48 + c], v[56 + c]);
     v[0] = v[0] - 1024.0f;
+}
+
+// The same on pairs.  In: a[(r / 2) * 8 + c] = (v[r][c], v[r + 1][c]) for even r, i.e. two
+// rows side by side, so that a row pass transforms both.  Out: b[r * 4 + c / 2] = (F[r][c],
+// F[r][c + 1]), two columns side by side after a column pass that transforms both.  Every
+// value sees exactly the operations of aan2d.
+__device__ __forceinline__ void aan2d_pairs(f2 (&a)[32], f2 (&b)[32]) {
+#pragma unroll
+    for (int rp = 0; rp < 4; ++rp)
+        aan1d(a[8 * rp], a[8 * rp + 1], a[8 * rp + 2], a[8 * rp + 3], a[8 * rp + 4], a[8 * rp + 5], a[8 * rp + 6],
+              a[8 * rp + 7]);
+#pragma unroll
+    for (int rp = 0; rp < 4; ++rp)
+#pragma unroll
+        for (int cp = 0; cp < 4; ++cp) {
+            const f2 p1 = a[8 * rp + 2 * cp], p2 = a[8 * rp + 2 * cp + 1];
+            b[(2 * rp) * 4 + cp] = (f2){p1.x, p2.x};
+            b[(2 * rp + 1) * 4 + cp] = (f2){p1.y, p2.y};
+        }
+#pragma unroll
+    for (int cp = 0; cp < 4; ++cp)
+        aan1d(b[cp], b[4 + cp], b[8 + cp], b[12 + cp], b[16 + cp], b[20 + cp], b[24 + cp], b[28 + cp]);
+    b[0].x = b[0].x - 1024.0f;
 }
 
 // One colour channel of one pixel (SIMD256.h:155-186).  The reference also adds the
@@ -229,6 +262,50 @@ __device__ __forceinline__ void pixel_ycbcr(const u32 (&raw)[6], int i, float& y
     cr = t + 0.5f;
 }
 
+// Pixel i of two rows at once: (row a, row b) pairs through the same arithmetic as pixel_ycbcr.
+__device__ __forceinline__ f2 unorm8_pair(u32 wa, u32 wb, int k) {
+    const f2 x = {(float)((wa >> (8 * k)) & 0xffu), (float)((wb >> (8 * k)) & 0xffu)};
+    return fma2(x, splat(INV255_HI), x * INV255_LO);
+}
+
+__device__ __forceinline__ void pixel_ycbcr_pair(const u32 (&ra)[6], const u32 (&rb)[6], int i, f2& y, f2& cb, f2& cr) {
+    const f2 r = unorm8_pair(ra[(3 * i) >> 2], rb[(3 * i) >> 2], (3 * i) & 3);
+    const f2 g = unorm8_pair(ra[(3 * i + 1) >> 2], rb[(3 * i + 1) >> 2], (3 * i + 1) & 3);
+    const f2 b = unorm8_pair(ra[(3 * i + 2) >> 2], rb[(3 * i + 2) >> 2], (3 * i + 2) & 3);
+    f2 t = r * 0.2990f;
+    t = t + g * 0.5870f;
+    y = t + b * 0.1140f;
+    t = r * -0.1687f;
+    t = t + g * -0.3312f;
+    t = t + b * 0.5000f;
+    cb = t + 0.5f;
+    t = r * 0.5000f;
+    t = t + g * -0.4186f;
+    t = t + b * -0.0813f;
+    cr = t + 0.5f;
+}
+
+// x255 (SIMD256.h:484-494), transform, quantize, zig-zag: row-pair values in, the block's
+// 32 dwords of int16 pairs out.
+__device__ __forceinline__ void transform_quantize_pairs(f2 (&a)[32], const float* __restrict__ rhi,
+                                                         const float* __restrict__ rlo, u32 (&p)[32]) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a[i] = a[i] * 255.0f;
+    f2 b[32];
+    aan2d_pairs(a, b);
+    float q[64];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {   // natural order, two neighbouring columns at a time
+        const f2 hi = {rhi[2 * i], rhi[2 * i + 1]}, lo = {rlo[2 * i], rlo[2 * i + 1]};
+        const f2 t = fma2(b[i], hi, b[i] * lo) + ROUND_MAGIC;
+        q[2 * i] = t.x;
+        q[2 * i + 1] = t.y;
+    }
+#pragma unroll
+    for (int z = 0; z < 64; z += 2)
+        p[z >> 1] = __builtin_amdgcn_perm(__float_as_uint(q[kZZ[z + 1]]), __float_as_uint(q[kZZ[z]]), 0x05040100u);
+}
+
 // Row of 8 pixels starting at (x0, y): one aligned 24-byte read inside the image,
 // byte-wise edge replication (Image.cpp:63-139) outside.
 __device__ __forceinline__ void load_row8(const unsigned char* __restrict__ rgb, long long stride, int x0, int y,
@@ -273,7 +350,7 @@ __device__ __forceinline__ void finish_block(float (&v)[64], const float* __rest
     for (int i = 0; i < 8; ++i) dst[i] = make_uint4(packed[4 * i], packed[4 * i + 1], packed[4 * i + 2], packed[4 * i + 3]);
 }
 
-// Same as finish_block, but the wave's 64 blocks go through LDS so that every store
+// Same as finish_block for row-pair values (see aan2d_pairs), and the wave's 64 blocks go through LDS so that every store
 // instruction writes whole 128-byte lines (8 lanes per block) instead of 64 scattered
 // 16-byte pieces.  `stage` is this wave's area of kRounds-th of 64 x 144 bytes (the 16
 // bytes of padding per block keep the 16-byte LDS accesses conflict free); with kRounds
@@ -283,22 +360,13 @@ __device__ __forceinline__ void finish_block(float (&v)[64], const float* __rest
 constexpr int kStagePitch = 144;
 
 template <int kRounds>
-__device__ __forceinline__ void finish_block_staged(float (&v)[64], const float* __restrict__ rhi,
+__device__ __forceinline__ void finish_block_staged(f2 (&a)[32], const float* __restrict__ rhi,
                                                     const float* __restrict__ rlo, unsigned char* stage,
                                                     int16_t* __restrict__ waveBase, int blockStride, int count) {
-#pragma unroll
-    for (int i = 0; i < 64; ++i) v[i] = v[i] * 255.0f;   // SIMD256.h:484-494
-    aan2d(v);
     const int lane = threadIdx.x & 63;
     constexpr int kPerRound = 64 / kRounds;
     u32 p[32];
-#pragma unroll
-    for (int z = 0; z < 64; z += 2) {
-        const int a = kZZ[z], b = kZZ[z + 1];
-        const float qa = __builtin_fmaf(v[a], rhi[a], v[a] * rlo[a]) + ROUND_MAGIC;
-        const float qb = __builtin_fmaf(v[b], rhi[b], v[b] * rlo[b]) + ROUND_MAGIC;
-        p[z >> 1] = __builtin_amdgcn_perm(__float_as_uint(qb), __float_as_uint(qa), 0x05040100u);
-    }
+    transform_quantize_pairs(a, rhi, rlo, p);
 #pragma unroll
     for (int round = 0; round < kRounds; ++round) {
         if (kRounds == 1 || lane / kPerRound == round) {
@@ -328,21 +396,12 @@ __device__ __forceinline__ void finish_block_staged(float (&v)[64], const float*
 // Luma variant for the 4:2:0 kernel: lane l holds block (l & 3) of the wave's MCU (l >> 2);
 // an MCU's four luma blocks are contiguous (512 bytes), MCUs are six blocks apart.  Two
 // half-wave rounds through a 32-block stage.
-__device__ __forceinline__ void finish_block_staged_y(float (&v)[64], const float* __restrict__ rhi,
+__device__ __forceinline__ void finish_block_staged_y(f2 (&a)[32], const float* __restrict__ rhi,
                                                       const float* __restrict__ rlo, unsigned char* stage,
                                                       int16_t* __restrict__ waveBase, int mcuCount) {
-#pragma unroll
-    for (int i = 0; i < 64; ++i) v[i] = v[i] * 255.0f;   // SIMD256.h:484-494
-    aan2d(v);
     const int lane = threadIdx.x & 63;
     u32 p[32];
-#pragma unroll
-    for (int z = 0; z < 64; z += 2) {
-        const int a = kZZ[z], b = kZZ[z + 1];
-        const float qa = __builtin_fmaf(v[a], rhi[a], v[a] * rlo[a]) + ROUND_MAGIC;
-        const float qb = __builtin_fmaf(v[b], rhi[b], v[b] * rlo[b]) + ROUND_MAGIC;
-        p[z >> 1] = __builtin_amdgcn_perm(__float_as_uint(qb), __float_as_uint(qa), 0x05040100u);
-    }
+    transform_quantize_pairs(a, rhi, rlo, p);
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
         if ((lane >> 5) == round) {
@@ -392,8 +451,10 @@ __global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned c
         rgb += locate_mcu(g, m, mx, my);
         const int x0 = mx * 16 + (q & 1) * 8, y0 = my * 16 + (q >> 1) * 8;
         const bool interior = x0 + 8 <= g.W && y0 + 8 <= g.rowsAvail;
-        float v[64];
-        float* cbDst = chroma + ml * kChromaPitch + (q >> 1) * 32 + (q & 1) * 4;
+        f2 a[32];   // a[rp * 8 + i] = Y of pixel i in rows 2rp and 2rp + 1
+        // Chroma blocks in LDS hold their rows in pairs as well: value (r, c) at
+        // (r / 2) * 16 + c * 2 + (r & 1), so the chroma waves read row-pair values directly.
+        float* cbDst = chroma + ml * kChromaPitch + (q >> 1) * 32 + (q & 1) * 8;
         float* crDst = cbDst + k420Mcus * kChromaPitch;
         // All sixteen row loads are issued before the first conversion, so one memory
         // latency is paid per thread instead of one per row.
@@ -401,28 +462,36 @@ __global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned c
 #pragma unroll
         for (int r = 0; r < 8; ++r) load_row8(rgb, g.strideBytes, x0, y0 + r, interior, g.W, g.rowsAvail, raw[r]);
         __builtin_amdgcn_sched_barrier(0);
+        float ecb[4], ecr[4];   // chroma row of the even row pair, waiting for its odd partner
 #pragma unroll
         for (int rp = 0; rp < 4; ++rp) {
-            float hcb[2][4], hcr[2][4];
+            f2 cb[8], cr[8];
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int r = 2 * rp + rr;
-                float cb[8], cr[8];
+            for (int i = 0; i < 8; ++i) pixel_ycbcr_pair(raw[2 * rp], raw[2 * rp + 1], i, a[8 * rp + i], cb[i], cr[i]);
+            float ocb[4], ocr[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) pixel_ycbcr(raw[r], i, v[8 * r + i], cb[i], cr[i]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {   // (a + b) / 2.0f, SIMD256.h:260-277
-                    hcb[rr][j] = (cb[2 * j] + cb[2 * j + 1]) * 0.5f;
-                    hcr[rr][j] = (cr[2 * j] + cr[2 * j + 1]) * 0.5f;
-                }
+            for (int j = 0; j < 4; ++j) {
+                // (a + b) / 2.0f across, both rows at once (SIMD256.h:260-277), then
+                // (row0 + row1) / 2.0f down (SIMD256.h:295-304).
+                const f2 hcb = (cb[2 * j] + cb[2 * j + 1]) * 0.5f;
+                const f2 hcr = (cr[2 * j] + cr[2 * j + 1]) * 0.5f;
+                ocb[j] = (hcb.x + hcb.y) * 0.5f;
+                ocr[j] = (hcr.x + hcr.y) * 0.5f;
             }
-            float4 ocb, ocr;   // (row0 + row1) / 2.0f, SIMD256.h:295-304
-            ocb.x = (hcb[0][0] + hcb[1][0]) * 0.5f; ocb.y = (hcb[0][1] + hcb[1][1]) * 0.5f;
-            ocb.z = (hcb[0][2] + hcb[1][2]) * 0.5f; ocb.w = (hcb[0][3] + hcb[1][3]) * 0.5f;
-            ocr.x = (hcr[0][0] + hcr[1][0]) * 0.5f; ocr.y = (hcr[0][1] + hcr[1][1]) * 0.5f;
-            ocr.z = (hcr[0][2] + hcr[1][2]) * 0.5f; ocr.w = (hcr[0][3] + hcr[1][3]) * 0.5f;
-            *(float4*)(cbDst + rp * 8) = ocb;
-            *(float4*)(crDst + rp * 8) = ocr;
+            if ((rp & 1) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ecb[j] = ocb[j];
+                    ecr[j] = ocr[j];
+                }
+            } else {   // chroma rows (q >> 1) * 4 + rp - 1 and + rp form a pair
+                float* db = cbDst + (rp >> 1) * 16;
+                float* dr = crDst + (rp >> 1) * 16;
+                *(float4*)db = make_float4(ecb[0], ocb[0], ecb[1], ocb[1]);
+                *(float4*)(db + 4) = make_float4(ecb[2], ocb[2], ecb[3], ocb[3]);
+                *(float4*)dr = make_float4(ecr[0], ocr[0], ecr[1], ocr[1]);
+                *(float4*)(dr + 4) = make_float4(ecr[2], ocr[2], ecr[3], ocr[3]);
+            }
             __builtin_amdgcn_sched_barrier(0);   // keep the row pairs in order: bounds live registers
         }
         // The wave's 64 luma blocks are 16 MCUs x 4: consecutive lanes, consecutive blocks
@@ -430,20 +499,21 @@ __global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned c
         // (l >> 2) * 6 + (l & 3) blocks from the wave's first; staged stores take a uniform
         // stride, so the four blocks of an MCU are addressed through their MCU.
         const int waveMcus = mcuCount - wave * 16;   // MCUs of this wave that exist (may be <= 0)
-        finish_block_staged_y(v, rhi, rlo, stage + wave * 32 * kStagePitch, coef + (mBase + wave * 16) * 6 * 64,
+        finish_block_staged_y(a, rhi, rlo, stage + wave * 32 * kStagePitch, coef + (mBase + wave * 16) * 6 * 64,
                               waveMcus);
     }
     __syncthreads();
     if (tid < 2 * k420Mcus) {
         const int ch = wave;   // wave 0: Cb, wave 1: Cr
         const float4* src = (const float4*)(chroma + (ch * k420Mcus + (tid & 63)) * kChromaPitch);
-        float v[64];
+        f2 a[32];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float4 t = src[i];
-            v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+            a[2 * i] = (f2){t.x, t.y};
+            a[2 * i + 1] = (f2){t.z, t.w};
         }
-        finish_block_staged<2>(v, rhi + 64 * (1 + ch), rlo + 64 * (1 + ch), stage + wave * 32 * kStagePitch,
+        finish_block_staged<2>(a, rhi + 64 * (1 + ch), rlo + 64 * (1 + ch), stage + wave * 32 * kStagePitch,
                                coef + (mBase * 6 + 4 + ch) * 64, 6, mcuCount);
     }
 }
@@ -481,22 +551,22 @@ __global__ __launch_bounds__(3 * k444Positions) void k_transform_444(KGeom g, co
 #pragma unroll
     for (int r = 0; r < 8; ++r) load_row8(rgb, g.strideBytes, x0, y0 + r, interior, g.W, g.rowsAvail, raw[r]);
     __builtin_amdgcn_sched_barrier(0);
-    float v[64];
+    f2 a[32];   // a[rp * 8 + i]: pixel i of rows 2rp and 2rp + 1
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int rp = 0; rp < 4; ++rp) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float rr = unorm8(raw[r][(3 * i) >> 2], (3 * i) & 3);
-            const float gg = unorm8(raw[r][(3 * i + 1) >> 2], (3 * i + 1) & 3);
-            const float bb = unorm8(raw[r][(3 * i + 2) >> 2], (3 * i + 2) & 3);
-            float t = m0 * rr;
-            t = t + m1 * gg;
-            t = t + m2 * bb;
-            v[8 * r + i] = t + bias;
+            const f2 rr = unorm8_pair(raw[2 * rp][(3 * i) >> 2], raw[2 * rp + 1][(3 * i) >> 2], (3 * i) & 3);
+            const f2 gg = unorm8_pair(raw[2 * rp][(3 * i + 1) >> 2], raw[2 * rp + 1][(3 * i + 1) >> 2], (3 * i + 1) & 3);
+            const f2 bb = unorm8_pair(raw[2 * rp][(3 * i + 2) >> 2], raw[2 * rp + 1][(3 * i + 2) >> 2], (3 * i + 2) & 3);
+            f2 t = rr * m0;
+            t = t + gg * m1;
+            t = t + bb * m2;
+            a[8 * rp + i] = t + bias;
         }
-        __builtin_amdgcn_sched_barrier(0);   // row by row: bounds the live registers
+        __builtin_amdgcn_sched_barrier(0);   // row pair by row pair: bounds the live registers
     }
-    finish_block_staged<1>(v, rhi, rlo, stage + c * 64 * kStagePitch, coef + (m0w * 3 + c) * 64, 3, count);
+    finish_block_staged<1>(a, rhi, rlo, stage + c * 64 * kStagePitch, coef + (m0w * 3 + c) * 64, 3, count);
 }
 
 static bool scheme_is(const KGeom& g, int wf, int hf, int method) {
