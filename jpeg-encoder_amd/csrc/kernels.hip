@@ -628,33 +628,30 @@ __device__ __forceinline__ void walk_block(const u32 (&w)[32], int pred, Visitor
     const int diff = coef_at(w, 0) - pred;
     const int dcat = bit_category(diff);
     vis.dc(dcat, (u32)(diff < 0 ? diff - 1 : diff) & ((1u << dcat) - 1u));
-    int run = 0;
+    int last = 0;   // index of the last non-zero coefficient seen (the DC term counts)
     // Eight coefficients (one 16-byte load) at a time: groups that are all zero -- most of
-    // the high-frequency half of a typical block -- only extend the run.
+    // the high-frequency half of a typical block -- are skipped.  A zero coefficient costs
+    // nothing but the test: the run in front of a non-zero one is the distance to `last`.
 #pragma unroll
     for (int grp = 0; grp < 8; ++grp) {
         const u32 any = (grp == 0 ? (w[0] & 0xffff0000u) : w[4 * grp]) | w[4 * grp + 1] | w[4 * grp + 2] | w[4 * grp + 3];
-        if (any == 0) {
-            run += grp == 0 ? 7 : 8;
-            continue;
-        }
+        if (any == 0) continue;
 #pragma unroll
         for (int i = 8 * grp + (grp == 0 ? 1 : 0); i < 8 * grp + 8; ++i) {
             const int v = coef_at(w, i);
             if (v != 0) {
+                int run = i - 1 - last;
+                last = i;
                 if (run > 15) {
                     vis.zrl(run >> 4);
                     run &= 15;
                 }
                 const int cat = bit_category(v);
                 vis.ac((run << 4) | cat, cat, (u32)(v < 0 ? v - 1 : v) & ((1u << cat) - 1u));
-                run = 0;
-            } else {
-                ++run;
             }
         }
     }
-    if (run != 0) vis.eob();
+    if (last != 63) vis.eob();
 }
 
 __device__ __forceinline__ void load_block(const int16_t* coef, long long b, u32 (&w)[32]) {
