@@ -153,6 +153,18 @@ int jpeg_hip_upload_pixels(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_form
  * transform has run. */
 int jpeg_hip_bind_pixels(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes);
 
+/* Pixel filters on the context's RGB pixels, before the transform: Image::applySepia
+ * (Image.cpp:212-219, matrix and operation order of applySepiaFilterAVXImpl,
+ * SIMD256.h:218-244) and Encoder::multiplyColorChannelBy while the channels still are R, G, B
+ * (Encoder.cpp:35-38, multiplyAVX, SIMD256.h:246-258).  The result is kept as float pixels
+ * in the context (byte pixels are divided by 255.0f first, ImageLoader.cpp:190-193) and is
+ * what the next jpeg_hip_transform reads.  channel: 0 R, 1 G, 2 B (ignored for sepia). */
+enum { JPEG_HIP_FILTER_SEPIA = 0, JPEG_HIP_FILTER_MULTIPLY = 1 };
+int jpeg_hip_filter_pixels(jpeg_hip_ctx* ctx, int filter, int channel, float value);
+/* The context's current pixels as floats on the host (three per pixel, rows of the band),
+ * e.g. to look at a filter's result the way ImageLoader::SavePPM would. */
+int jpeg_hip_get_pixels(jpeg_hip_ctx* ctx, float* h_rgb, int64_t capacity_floats);
+
 /* convertToYCbCr + reduceResolutionBySchema + applyDCT(Y|Cb|Cr) + zig-zag as one fused
  * kernel (Encoder.cpp:15-23, 157-166, 229-258; SIMD256.h:155-186, 260-304, 470-522;
  * ZigZag.h:10-49).  stages: JPEG_HIP_STAGE_* bits for the two calls a caller may have

@@ -160,7 +160,7 @@ struct jpeg_hip_ctx {
     int fmt = JPEG_HIP_RGB8;
     int64_t stride = 0;
     DevBuf pixels, coef, qtab, hist, tables, ivOff, ffCount, ffOff, scanTmp, result, unstuffed,
-        staging, batchHdr, batchHdrLen, batchFfStart, tileState, decCoef, decPlanes, decTables, decRgb, decSum;
+        staging, batchHdr, batchHdrLen, batchFfStart, tileState, decCoef, decPlanes, decTables, decRgb, decSum, pixelsF;
     jpeghip::DecodedStream* decoded = nullptr;   // last file given to the verification decoder
     HostBuf hostHist, hostTables, hostHdr, hostHdrLen, hostOffsets;
     EntropyWorkspace ws;
@@ -463,7 +463,7 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->ffOff, &ctx->scanTmp, &ctx->result,
                       &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart,
-                      &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum};
+                      &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum, &ctx->pixelsF};
     delete ctx->decoded;
     for (DevBuf* b : bufs) b->release();
     HostBuf* hbufs[] = {&ctx->hostHist, &ctx->hostTables, &ctx->hostHdr, &ctx->hostHdrLen, &ctx->hostOffsets};
@@ -564,6 +564,47 @@ int jpeg_hip_upload_pixels(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_form
     ctx->stride = (int64_t)dstStride;
     ctx->hasPixels = true;
     ctx->transformed = false;
+    return JPEG_HIP_OK;
+}
+
+// Rows of pixels the band's RGB pointer covers.
+static int band_pixel_rows(const jpeg_hip_ctx* ctx) {
+    return std::min(band_rows_available(ctx->geo), ctx->geo.bandRows * ctx->geo.stepH);
+}
+
+int jpeg_hip_filter_pixels(jpeg_hip_ctx* ctx, int filter, int channel, float value) {
+    if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->begun || !ctx->hasPixels) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "filters need begin() and pixels");
+    if ((filter != JPEG_HIP_FILTER_SEPIA && filter != JPEG_HIP_FILTER_MULTIPLY) || channel < 0 || channel > 2)
+        return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "unknown filter or channel");
+    if (ctx->prm.standard_huffman)
+        return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "the standard Huffman tables cover 8-bit pixels only");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rows = band_pixel_rows(ctx), width = ctx->geo.width;
+    HIP_TRY(ctx, ctx->pixelsF.ensure((size_t)rows * width * 3 * sizeof(float)));
+    HIP_TRY(ctx, launch_pixel_filter(ctx->rgb, ctx->fmt, ctx->stride, (float*)ctx->pixelsF.p, width, rows, filter, channel,
+                                     value, ctx->stream));
+    ctx->rgb = ctx->pixelsF.p;
+    ctx->fmt = JPEG_HIP_RGBF32;
+    ctx->stride = (int64_t)width * 3 * sizeof(float);
+    ctx->transformed = false;
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_get_pixels(jpeg_hip_ctx* ctx, float* h_rgb, int64_t capacity_floats) {
+    if (!ctx || !h_rgb) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->begun || !ctx->hasPixels) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "no pixels");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rows = band_pixel_rows(ctx), width = ctx->geo.width;
+    const int64_t n = (int64_t)rows * width * 3;
+    if (capacity_floats < n) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "pixel buffer too small");
+    if (ctx->rgb != ctx->pixelsF.p) {   // convert a copy; the pixels in use stay as they are
+        HIP_TRY(ctx, ctx->pixelsF.ensure((size_t)n * sizeof(float)));
+        HIP_TRY(ctx, launch_pixel_filter(ctx->rgb, ctx->fmt, ctx->stride, (float*)ctx->pixelsF.p, width, rows, -1, 0, 0.0f,
+                                         ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(h_rgb, ctx->pixelsF.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, wait_stream(ctx));
     return JPEG_HIP_OK;
 }
 

@@ -71,6 +71,11 @@ constexpr int kStuffChunk = 4096;   // unstuffed bytes handled by one workgroup 
 // Fused colour conversion + subsampling + DCT + quantization + zig-zag.
 hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef, hipStream_t s);
 
+// Pixel filter (JPEG_HIP_FILTER_*) over `rows` rows of `width` pixels: src in sampleFormat
+// with srcStride bytes per row, dst float RGB with 3 * width floats per row (may be src).
+hipError_t launch_pixel_filter(const void* d_src, int sampleFormat, long long srcStride, float* d_dst, int width, int rows,
+                               int filter, int channel, float value, hipStream_t s);
+
 // Symbol histograms (uint64[4][256] per image of the batch); d_hist is cleared first.
 hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, unsigned long long* d_hist, hipStream_t s);
 

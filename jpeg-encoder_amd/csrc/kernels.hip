@@ -569,6 +569,45 @@ __global__ __launch_bounds__(3 * k444Positions) void k_transform_444(KGeom g, co
     finish_block_staged<1>(a, rhi, rlo, stage + c * 64 * kStagePitch, coef + (m0w * 3 + c) * 64, 3, count);
 }
 
+// Pixel filters in front of the transform.  One thread per pixel; in place when src == dst.
+// filter < 0 only converts to float.
+__global__ __launch_bounds__(256) void k_pixel_filter(const void* __restrict__ src, int fmt, long long srcStride,
+                                                      float* __restrict__ dst, int width, int filter, int channel,
+                                                      float value) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= width) return;
+    float r, g, b;
+    load_pixel(src, srcStride, fmt, x, y, r, g, b);
+    float o[3] = {r, g, b};
+    if (filter == JPEG_HIP_FILTER_SEPIA) {   // applySepiaFilterAVXImpl, SIMD256.h:218-244; its "+ 0 * 1" adds +0.0f
+        float t = 0.3930f * r;
+        t = t + 0.7690f * g;
+        t = t + 0.1890f * b;
+        o[0] = t + 0.0f;
+        t = 0.3490f * r;
+        t = t + 0.6860f * g;
+        t = t + 0.1680f * b;
+        o[1] = t + 0.0f;
+        t = 0.2720f * r;
+        t = t + 0.5340f * g;
+        t = t + 0.1310f * b;
+        o[2] = t + 0.0f;
+    } else if (filter == JPEG_HIP_FILTER_MULTIPLY) {   // multiplyAVX, SIMD256.h:246-258
+        o[channel] = o[channel] * value;
+    }
+    float* p = dst + ((long long)y * width + x) * 3;
+    p[0] = o[0];
+    p[1] = o[1];
+    p[2] = o[2];
+}
+
+hipError_t launch_pixel_filter(const void* d_src, int sampleFormat, long long srcStride, float* d_dst, int width, int rows,
+                               int filter, int channel, float value, hipStream_t s) {
+    hipLaunchKernelGGL(k_pixel_filter, dim3((unsigned)((width + 255) / 256), (unsigned)rows), dim3(256), 0, s, d_src,
+                       sampleFormat, srcStride, d_dst, width, filter, channel, value);
+    return hipGetLastError();
+}
+
 static bool scheme_is(const KGeom& g, int wf, int hf, int method) {
     if (g.wf[0] != 1 || g.hf[0] != 1) return false;
     for (int c = 1; c < 3; ++c) {

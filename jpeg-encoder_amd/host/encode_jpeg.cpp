@@ -1,6 +1,7 @@
 // Command line driver that replays the reference's EncodeJPEG call sequence
 // (JPEG-Encoder-SIMD.cpp:397-441) on the GPU-backed classes:
-//   encode_jpeg <source .ppm/.png> <destination .jpg> [444|422|411|420] [quality 1..100]
+//   encode_jpeg <source .ppm/.png> <destination .jpg> [444|422|411|420] [quality 1..100 | 0 = Annex K tables]
+//               [options: sepia, gain=<channel 0..2>:<factor>, standard-huffman, restart=<MCUs>]
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -9,14 +10,24 @@
 #include "Encoder.h"
 #include "ImageLoader.h"
 
+struct Options {
+    bool sepia = false, standardHuffman = false;
+    int gainChannel = -1, restart = 0;
+    float gain = 1.0f;
+};
+
 static void EncodeJPEG(const std::string& srcFile, const std::string& dstFile, const SamplingDefinition& scheme,
-                       const QTableSet& qtables) {
+                       const QTableSet& qtables, const Options& opt) {
     ImagePtr image = ImageLoader::Load(srcFile, scheme);
     if (!image) {
         std::cout << "Failed to load source image " << srcFile << std::endl;
         exit(2);
     }
     EncoderPtr encoder = std::make_shared<Encoder>(image, qtables);
+    if (opt.sepia) encoder->applySepia();
+    if (opt.gainChannel >= 0) encoder->multiplyColorChannelBy((ColorChannelName)opt.gainChannel, opt.gain);
+    encoder->setStandardHuffmanTables(opt.standardHuffman);
+    encoder->setRestartInterval(opt.restart);
     encoder->convertToYCbCr();
     encoder->reduceResolutionBySchema();
     encoder->applyDCT(YCbCrColorName::Y);
@@ -35,13 +46,27 @@ int main(int argc, char* argv[]) {
                                        : name == "422" ? Sampling::Scheme422
                                        : name == "411" ? Sampling::Scheme411
                                                        : Sampling::Scheme420;
+    Options opt;
+    for (int i = 5; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "sepia") opt.sepia = true;
+        else if (a == "standard-huffman") opt.standardHuffman = true;
+        else if (a.rfind("restart=", 0) == 0) opt.restart = atoi(a.c_str() + 8);
+        else if (a.rfind("gain=", 0) == 0 && a.size() > 7 && a[6] == ':') {
+            opt.gainChannel = a[5] - '0';
+            opt.gain = (float)atof(a.c_str() + 7);
+        } else {
+            std::cerr << "unknown option " << a << std::endl;
+            return 1;
+        }
+    }
     try {
-        if (argc > 4) {
+        if (argc > 4 && atoi(argv[4]) > 0) {
             const QTable lum = JPEGQuantization::scaledLuminance(atoi(argv[4]));
             const QTable chr = JPEGQuantization::scaledChrominance(atoi(argv[4]));
-            EncodeJPEG(argv[1], argv[2], scheme, QTableSet(lum, chr));
+            EncodeJPEG(argv[1], argv[2], scheme, QTableSet(lum, chr), opt);
         } else {
-            EncodeJPEG(argv[1], argv[2], scheme, QTableSet(JPEGQuantization::luminance, JPEGQuantization::chrominance));
+            EncodeJPEG(argv[1], argv[2], scheme, QTableSet(JPEGQuantization::luminance, JPEGQuantization::chrominance), opt);
         }
     } catch (const std::exception& e) {
         std::cerr << "encode failed: " << e.what() << std::endl;

@@ -256,6 +256,25 @@ void Image::setPixel(size_t x, size_t y, const PixelData32& c) {
     pixels8.clear();
 }
 
+void Image::applySepia() {
+    for (size_t i = 0; i + 2 < pixels.size(); i += 3) {
+        const float r = pixels[i], g = pixels[i + 1], b = pixels[i + 2];
+        float t = 0.3930f * r;
+        t = t + 0.7690f * g;
+        t = t + 0.1890f * b;
+        pixels[i] = t + 0.0f;   // the matrix's fourth column times alpha = 1
+        t = 0.3490f * r;
+        t = t + 0.6860f * g;
+        t = t + 0.1680f * b;
+        pixels[i + 1] = t + 0.0f;
+        t = 0.2720f * r;
+        t = t + 0.5340f * g;
+        t = t + 0.1310f * b;
+        pixels[i + 2] = t + 0.0f;
+    }
+    pixels8.clear();
+}
+
 std::vector<float> Image::getRawPixelData() {
     std::vector<float> out(imageSize.width * imageSize.height * 4);   // sized as the reference does; 3 used per pixel
     std::copy(pixels.begin(), pixels.end(), out.begin());
@@ -310,6 +329,17 @@ Encoder::~Encoder() { jpeg_hip_destroy(ctx); }
 void Encoder::convertToYCbCr() { stages |= JPEG_HIP_STAGE_YCBCR; }
 void Encoder::reduceResolutionBySchema() { stages |= JPEG_HIP_STAGE_SUBSAMPLE; }
 
+void Encoder::multiplyColorChannelBy(ColorChannelName channel, float val) {
+    if (stages != 0 || transformed)
+        throw std::runtime_error("multiplyColorChannelBy is supported on the R, G, B channels only (before convertToYCbCr)");
+    pixelOps.push_back({JPEG_HIP_FILTER_MULTIPLY, (int)channel, val});
+}
+
+void Encoder::applySepia() {
+    if (stages != 0 || transformed) throw std::runtime_error("applySepia works on RGB pixels (before convertToYCbCr)");
+    pixelOps.push_back({JPEG_HIP_FILTER_SEPIA, 0, 0.0f});
+}
+
 void Encoder::ensureTransformed() {
     if (transformed) return;
     check(jpeg_hip_begin(ctx, &params), "jpeg_hip_begin");
@@ -320,6 +350,8 @@ void Encoder::ensureTransformed() {
         check(jpeg_hip_upload_pixels(ctx, image->pixels.data(), JPEG_HIP_RGBF32,
                                      (int64_t)image->imageSize.width * 3 * sizeof(float)),
               "jpeg_hip_upload_pixels");
+    for (const PixelOp& op : pixelOps)
+        check(jpeg_hip_filter_pixels(ctx, op.filter, op.channel, op.value), "jpeg_hip_filter_pixels");
     check(jpeg_hip_transform(ctx, stages), "jpeg_hip_transform");
     transformed = true;
 }

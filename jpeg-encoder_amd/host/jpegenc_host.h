@@ -237,6 +237,9 @@ public:
     void setPixel(size_t x, size_t y, const PixelData32& color);
     void getPixel(PixelData32& ref, size_t x, size_t y) const;  // outside the real image: nearest edge pixel
     bool hasBytePixels() const { return !pixels8.empty(); }
+    // Image.cpp:212-219 with the matrix and operation order of applySepiaFilterAVXImpl
+    // (SIMD256.h:218-244), on the host copy of the pixels.
+    void applySepia();
 };
 typedef std::shared_ptr<Image> ImagePtr;
 
@@ -255,6 +258,11 @@ private:
     bool dctDone[3];
     bool tablesReady;
     HuffmanTablePtr<byte> huffmanTables[2][2];
+    struct PixelOp {
+        int filter, channel;
+        float value;
+    };
+    std::vector<PixelOp> pixelOps;   // applied on the device, in order, after the upload
     void open(const QTableSet& qtables);
     void ensureTransformed();
     void ensureTables();
@@ -269,6 +277,9 @@ public:
     Encoder& operator=(const Encoder&) = delete;
 
     void convertToYCbCr();
+    // Encoder.cpp:35-38.  Supported while the channels still are R, G, B, i.e. before
+    // convertToYCbCr; runs on the GPU right after the pixels are uploaded.
+    void multiplyColorChannelBy(ColorChannelName colorChannel, float val);
     void reduceResolutionBySchema();
     void applyDCT(ColorChannelName colorChannelName);
     HuffmanTablePtr<byte> getHuffmanTable(CoefficientType type, ColorChannelName channelName);
@@ -276,6 +287,8 @@ public:
     void serializeScanData(BitBuffer& bitBuffer);
 
     // Extensions without a counterpart in the reference.
+    void applySepia();   // Image::applySepia on the encoder's device copy of the pixels
+    void setStandardHuffmanTables(bool on) { params.standard_huffman = on ? 1 : 0; }
     void setRestartInterval(int mcus) { params.restart_interval = mcus; }
     void setPadWithOnes(bool on) { params.pad_ones = on ? 1 : 0; }
     // Quantized coefficients of one channel: blocks in MCU order, 64 zig-zag values each.

@@ -12,6 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.abspath(os.path.join(_PKG, "..", "..", "lib", "libjpegenc_hip.so"))
 
 OK = 0
+FILTER_SEPIA, FILTER_MULTIPLY = 0, 1
 ERR_INVALID_ARGUMENT, ERR_HIP, ERR_BUFFER_TOO_SMALL, ERR_BAD_STATE, ERR_NO_DEVICE = -1, -2, -3, -4, -5
 RGB8, RGBF32 = 0, 1
 STAGE_YCBCR, STAGE_SUBSAMPLE, STAGE_ALL = 1, 2, 3
@@ -26,7 +27,7 @@ EXPORTS = [
     "jpeg_hip_get_coefficients",
     "jpeg_hip_coefficients_device", "jpeg_hip_analyze_band", "jpeg_hip_finish_band", "jpeg_hip_set_profiling",
     "jpeg_hip_get_timings", "jpeg_hip_decode_info", "jpeg_hip_decode", "jpeg_hip_decode_host",
-    "jpeg_hip_decoded_coefficients", "jpeg_hip_psnr",
+    "jpeg_hip_decoded_coefficients", "jpeg_hip_psnr", "jpeg_hip_filter_pixels", "jpeg_hip_get_pixels",
 ]
 
 
@@ -95,6 +96,8 @@ def lib():
         L.jpeg_hip_upload_pixels.argtypes = [vp, vp, i32, i64]
         L.jpeg_hip_bind_pixels.argtypes = [vp, vp, i32, i64]
         L.jpeg_hip_transform.argtypes = [vp, i32]
+        L.jpeg_hip_filter_pixels.argtypes = [vp, i32, i32, C.c_float]
+        L.jpeg_hip_get_pixels.argtypes = [vp, vp, i64]
         L.jpeg_hip_histograms.argtypes = [vp, vp]
         L.jpeg_hip_histograms_host.argtypes = [vp, vp]
         L.jpeg_hip_huffman_from_histogram.argtypes = [vp, vp, vp]
@@ -330,6 +333,15 @@ class Context:
 
     def set_profiling(self, enabled):
         self._check(lib().jpeg_hip_set_profiling(self._h, 1 if enabled else 0))
+
+    # ---- pixel filters ----
+    def filter_pixels(self, which, channel=0, value=1.0):
+        self._check(lib().jpeg_hip_filter_pixels(self._h, which, channel, value))
+
+    def get_pixels(self, width, rows):
+        out = np.zeros((rows, width, 3), np.float32)
+        self._check(lib().jpeg_hip_get_pixels(self._h, _np(out), out.size))
+        return out
 
     # ---- verification decoder ----
     def decode_host(self, jpeg):

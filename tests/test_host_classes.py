@@ -93,3 +93,34 @@ def test_ppm_with_other_maxval_uses_float_path(tmp_path):
     dst = tmp_path / "m.jpg"
     subprocess.check_call([os.path.join(LIB, "encode_jpeg"), str(src), str(dst), "420"])
     assert dst.read_bytes() == want
+
+
+@pytest.mark.gpu
+def test_driver_options_filters_tables_restarts(tmp_path):
+    from PIL import Image
+    F32 = np.float32
+    img = synth.generate("natural", 130, 70, seed=11)
+    src = tmp_path / "s.png"
+    Image.fromarray(img).save(src)
+    dst = tmp_path / "o.jpg"
+    exe = os.path.join(LIB, "encode_jpeg")
+    # sepia + gain on the red channel, applied to the float pixels before convertToYCbCr
+    f = img.astype(F32) / F32(255.0)
+    r, g, b = f[..., 0], f[..., 1], f[..., 2]
+    sep = np.zeros_like(f)
+    for c, (a0, a1, a2) in enumerate([(0.3930, 0.7690, 0.1890), (0.3490, 0.6860, 0.1680), (0.2720, 0.5340, 0.1310)]):
+        sep[..., c] = ((F32(a0) * r + F32(a1) * g) + F32(a2) * b) + F32(0.0)
+    sep[..., 0] = sep[..., 0] * F32(0.5)
+    subprocess.check_call([exe, str(src), str(dst), "420", "90", "sepia", "gain=0:0.5"])
+    assert dst.read_bytes() == O.encode(sep, T.SCHEME_420, T.quality_tables(90)).jpeg
+    # restart intervals through the class surface
+    subprocess.check_call([exe, str(src), str(dst), "444", "0", "restart=6"])
+    assert dst.read_bytes() == O.encode(img, T.SCHEME_444, T.STANDARD_TABLES, restart_interval=6).jpeg
+    # standard Huffman tables: decodes to the same pixels as the optimised file, no smaller
+    subprocess.check_call([exe, str(src), str(dst), "420", "90"])
+    opt = dst.read_bytes()
+    subprocess.check_call([exe, str(src), str(dst), "420", "90", "standard-huffman"])
+    std = dst.read_bytes()
+    assert len(std) >= len(opt)
+    import io
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(std))), np.asarray(Image.open(io.BytesIO(opt))))
