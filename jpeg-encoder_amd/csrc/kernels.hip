@@ -876,26 +876,40 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const TIn* __restri
     }
 }
 
-// One workgroup scans everything: for short inputs one launch beats three.
+// One workgroup scans everything: for short inputs one launch beats three.  1024 threads
+// with sixteen values each, all loaded before the first is used, so that a pass over 16384
+// values costs one memory latency.
+constexpr int kWideThreads = 1024;
+constexpr int kWideItems = 16;
+constexpr long long kSmallScanLimit = 4LL * kWideThreads * kWideItems;
+
 template <typename TIn>
-__global__ __launch_bounds__(kScanThreads) void k_scan_small(const TIn* __restrict__ in, long long nHost,
+__global__ __launch_bounds__(kWideThreads) void k_scan_small(const TIn* __restrict__ in, long long nHost,
                                                              const u64* __restrict__ dN, u64* __restrict__ out) {
-    __shared__ u64 lds[4];
+    __shared__ u64 waveTotal[kWideThreads / 64];
     const long long n = dN ? (long long)*dN : nHost;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     u64 carry = 0;
-    for (long long base0 = 0; base0 < n; base0 += kScanTile) {
-        const long long base = base0 + (long long)threadIdx.x * kScanItems;
-        u64 vals[kScanItems];
+    for (long long base0 = 0; base0 < n; base0 += kWideThreads * kWideItems) {
+        const long long base = base0 + (long long)threadIdx.x * kWideItems;
+        u64 vals[kWideItems];
         u64 s = 0;
 #pragma unroll
-        for (int i = 0; i < kScanItems; ++i) {
-            vals[i] = base + i < n ? (u64)in[base + i] : 0;
-            s += vals[i];
-        }
-        u64 total;
-        u64 run = carry + block_exclusive_scan(s, lds, total);
+        for (int i = 0; i < kWideItems; ++i) vals[i] = base + i < n ? (u64)in[base + i] : 0;
 #pragma unroll
-        for (int i = 0; i < kScanItems; ++i) {
+        for (int i = 0; i < kWideItems; ++i) s += vals[i];
+        const u64 inc = wave_inclusive_scan(s);
+        if (lane == 63) waveTotal[wave] = inc;
+        __syncthreads();
+        u64 before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < kWideThreads / 64; ++i) {
+            if (i < wave) before += waveTotal[i];
+            total += waveTotal[i];
+        }
+        u64 run = carry + before + inc - s;
+#pragma unroll
+        for (int i = 0; i < kWideItems; ++i) {
             if (base + i < n) out[base + i] = run;
             run += vals[i];
         }
@@ -905,13 +919,11 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_small(const TIn* __restri
     if (threadIdx.x == 0) out[n] = carry;
 }
 
-constexpr long long kSmallScanLimit = 32768;
-
 template <typename TIn>
 static hipError_t exclusive_scan(const TIn* in, long long nHost, const u64* dN, long long nMax, u64* tmp, u64* out,
                                  hipStream_t s, bool haveTileSums = false) {
     if (!haveTileSums && nMax <= kSmallScanLimit) {
-        hipLaunchKernelGGL(k_scan_small<TIn>, dim3(1), dim3(kScanThreads), 0, s, in, nHost, dN, out);
+        hipLaunchKernelGGL(k_scan_small<TIn>, dim3(1), dim3(kWideThreads), 0, s, in, nHost, dN, out);
         return hipGetLastError();
     }
     long long tiles = (nMax + kScanTile - 1) / kScanTile;
@@ -1366,23 +1378,27 @@ __device__ __forceinline__ u32 stuff_mask(const KGeom& g, const uint8_t* __restr
     return mask;
 }
 
+// One wave per 4 KiB chunk: four 16-byte pieces per lane in flight, a shuffle reduction, no
+// barriers.
 __global__ __launch_bounds__(256) void k_count_ff(KGeom g, const uint8_t* __restrict__ buf,
                                                   const u64* __restrict__ ivOff, const u64* __restrict__ result,
                                                   u32* __restrict__ ffCount) {
-    __shared__ u64 lds[4];
     const u64 bytes = result[2];
     const long long chunks = (long long)((bytes + kStuffChunk - 1) / kStuffChunk);
-    for (long long ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
-        const long long i0 = ch * kStuffChunk + (long long)threadIdx.x * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long ch = (long long)blockIdx.x * 4 + wave; ch < chunks; ch += (long long)gridDim.x * 4) {
         int cnt = 0;
-        if ((u64)i0 < bytes) {
-            uint4 q;
-            cnt = __popc(stuff_mask(g, buf, ivOff, bytes, i0, q));
+#pragma unroll
+        for (int k = 0; k < kStuffChunk / 1024; ++k) {
+            const long long i0 = ch * kStuffChunk + k * 1024 + lane * 16;
+            if ((u64)i0 < bytes) {
+                uint4 q;
+                cnt += __popc(stuff_mask(g, buf, ivOff, bytes, i0, q));
+            }
         }
-        u64 total;
-        block_exclusive_scan((u64)cnt, lds, total);
-        if (threadIdx.x == 0) ffCount[ch] = (u32)total;
-        __syncthreads();
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+        if (lane == 0) ffCount[ch] = (u32)cnt;
     }
 }
 
@@ -1567,11 +1583,16 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     else
         hipLaunchKernelGGL(k_encode_bits<false>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
                            ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed);
-    long long chunkGrid = ws.maxChunks < 2048 ? ws.maxChunks : 2048;
+    // Chunks the stream can have at most: from the bound that was cleared.
+    long long chunkBound = zero / kStuffChunk + 1;
+    if (chunkBound > ws.maxChunks) chunkBound = ws.maxChunks;
+    long long chunkGrid = chunkBound < 2048 ? chunkBound : 2048;
     if (chunkGrid < 1) chunkGrid = 1;
-    hipLaunchKernelGGL(k_count_ff, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.result,
+    long long countGrid = (chunkBound + 3) / 4;
+    countGrid = countGrid < 1 ? 1 : (countGrid > 4096 ? 4096 : countGrid);
+    hipLaunchKernelGGL(k_count_ff, dim3((unsigned)countGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.result,
                        ws.ffCount);
-    e = exclusive_scan<u32>(ws.ffCount, 0, ws.result + 3, ws.maxChunks, ws.scanTmp, ws.ffOff, s);
+    e = exclusive_scan<u32>(ws.ffCount, 0, ws.result + 3, chunkBound, ws.scanTmp, ws.ffOff, s);
     if (e != hipSuccess) return e;
     if (bo) {
         hipLaunchKernelGGL(k_image_ff_start, dim3((unsigned)(g.batch + 1)), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
