@@ -140,6 +140,14 @@ int jpeg_hip_encode_batch(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_forma
                           int64_t image_stride_bytes, int count, const jpeg_hip_params* params, uint8_t* d_out,
                           int64_t slot_bytes, int64_t* h_lens);
 
+/* The same with frames and files in host memory (PCIe time included): the frames travel in
+ * passes through pinned staging, and the upload of one pass overlaps the encode of the
+ * pass before it.  This is the ingest half of the reference's loop (ImageLoader pixels ->
+ * Encoder, JPEG-Encoder-SIMD.cpp:404-437) for callers that hold decoded frames. */
+int jpeg_hip_encode_batch_host(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format, int64_t stride_bytes,
+                               int64_t image_stride_bytes, int count, const jpeg_hip_params* params, uint8_t* h_out,
+                               int64_t slot_bytes, int64_t* h_lens);
+
 /* ---- staged entry points (what the host Encoder class drives) --------------------------- */
 
 /* Image(w, h, scheme) + Encoder(image, qtables): fixes geometry and tables, sizes the

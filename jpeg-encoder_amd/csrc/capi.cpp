@@ -7,6 +7,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -160,9 +161,11 @@ struct jpeg_hip_ctx {
     int fmt = JPEG_HIP_RGB8;
     int64_t stride = 0;
     DevBuf pixels, coef, qtab, hist, tables, ivOff, ffCount, ffOff, scanTmp, result, unstuffed,
-        staging, batchHdr, batchHdrLen, batchFfStart, tileState, decCoef, decPlanes, decTables, decRgb, decSum, pixelsF;
+        staging, batchHdr, batchHdrLen, batchFfStart, tileState, decCoef, decPlanes, decTables, decRgb, decSum, pixelsF, pipeIn[2], pipeOut;
     jpeghip::DecodedStream* decoded = nullptr;   // last file given to the verification decoder
-    HostBuf hostHist, hostTables, hostHdr, hostHdrLen, hostOffsets;
+    HostBuf hostHist, hostTables, hostHdr, hostHdrLen, hostOffsets, pipeStage[2];
+    hipStream_t copyStream = nullptr;
+    hipEvent_t pipeEvent[2] = {nullptr, nullptr};
     EntropyWorkspace ws;
     Pinned* pin = nullptr;
     uint8_t lengths[4][256];
@@ -463,10 +466,15 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->ffOff, &ctx->scanTmp, &ctx->result,
                       &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart,
-                      &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum, &ctx->pixelsF};
+                      &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum, &ctx->pixelsF, &ctx->pipeIn[0], &ctx->pipeIn[1],
+                      &ctx->pipeOut};
     delete ctx->decoded;
     for (DevBuf* b : bufs) b->release();
-    HostBuf* hbufs[] = {&ctx->hostHist, &ctx->hostTables, &ctx->hostHdr, &ctx->hostHdrLen, &ctx->hostOffsets};
+    HostBuf* hbufs[] = {&ctx->hostHist, &ctx->hostTables, &ctx->hostHdr, &ctx->hostHdrLen, &ctx->hostOffsets,
+                        &ctx->pipeStage[0], &ctx->pipeStage[1]};
+    for (auto& e : ctx->pipeEvent)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->copyStream) (void)hipStreamDestroy(ctx->copyStream);
     for (HostBuf* b : hbufs) b->release();
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
@@ -954,17 +962,19 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
 
 }  // namespace
 
-extern "C" int jpeg_hip_encode_batch(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
-                                     int64_t image_stride_bytes, int count, const jpeg_hip_params* params, uint8_t* d_out,
-                                     int64_t slot_bytes, int64_t* h_lens) {
-    if (!ctx || !params || !d_out || !h_lens) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+namespace {
+
+// Checks a batch request, binds the first image's pixels for the checks that need them and
+// sizes the workspace; *passFrames receives the number of frames a pass may hold.
+int prepare_batch(jpeg_hip_ctx* ctx, const void* rgb, int sample_format, int64_t stride_bytes, int64_t image_stride_bytes,
+                  int count, const jpeg_hip_params* params, int64_t slot_bytes, int maxPass, int* passFrames) {
     if (count < 1) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "batch count must be at least 1");
     if (params->restart_interval != 0 || params->mcu_row_begin != 0 || params->mcu_row_end != 0)
         return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "batch images are whole images without restart intervals");
     if (slot_bytes < kBatchHeaderPitch) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "output slots are smaller than the headers");
     int st = jpeg_hip_begin(ctx, params);
     if (st != JPEG_HIP_OK) return st;
-    st = jpeg_hip_bind_pixels(ctx, d_rgb, sample_format, stride_bytes);
+    st = jpeg_hip_bind_pixels(ctx, rgb, sample_format, stride_bytes);
     if (st != JPEG_HIP_OK) return st;
     const Geometry& g = ctx->geo;
     const int64_t minImage = stride_bytes * (int64_t)(g.height - 1) + (int64_t)g.width * 3 * bytes_per_sample(sample_format);
@@ -973,6 +983,7 @@ extern "C" int jpeg_hip_encode_batch(jpeg_hip_ctx* ctx, const void* d_rgb, int s
     if (sample_format == JPEG_HIP_RGBF32 && image_stride_bytes % 4 != 0)
         return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "float pixels must be 4-byte aligned");
     int64_t perPass = kBatchMaxBlocks / g.totalBlocks;
+    if (perPass > maxPass) perPass = maxPass;
     if (perPass < 1) perPass = 1;
     if (perPass > count) perPass = count;
     const int pass = (int)perPass;
@@ -987,17 +998,126 @@ extern "C" int jpeg_hip_encode_batch(jpeg_hip_ctx* ctx, const void* d_rgb, int s
     HIP_TRY(ctx, ctx->hostHdrLen.ensure((size_t)pass * 4));
     HIP_TRY(ctx, ctx->hostOffsets.ensure((size_t)(2 * (pass + 1) + 4) * 8));
     ctx->times[0] = ctx->times[1] = ctx->times[2] = ctx->times[3] = 0;
+    *passFrames = pass;
+    return JPEG_HIP_OK;
+}
+
+void leave_batch(jpeg_hip_ctx* ctx) {   // the context no longer describes a single image
+    ctx->hasPixels = false;
+    ctx->transformed = false;
+    ctx->hasTables = false;
+    ctx->stagedScanLen = -1;
+}
+
+}  // namespace
+
+extern "C" int jpeg_hip_encode_batch(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
+                                     int64_t image_stride_bytes, int count, const jpeg_hip_params* params, uint8_t* d_out,
+                                     int64_t slot_bytes, int64_t* h_lens) {
+    if (!ctx || !params || !d_out || !h_lens) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    int pass = 0;
+    int st = prepare_batch(ctx, d_rgb, sample_format, stride_bytes, image_stride_bytes, count, params, slot_bytes, 1 << 30,
+                           &pass);
+    if (st != JPEG_HIP_OK) return st;
     for (int first = 0; first < count; first += pass) {
         const int n = count - first < pass ? count - first : pass;
         st = encode_batch_pass(ctx, (const uint8_t*)d_rgb + (int64_t)first * image_stride_bytes, image_stride_bytes, n,
                                d_out + (int64_t)first * slot_bytes, slot_bytes, h_lens + first);
         if (st != JPEG_HIP_OK) return st;
     }
-    // The context no longer describes a single image.
-    ctx->transformed = false;
-    ctx->hasTables = false;
-    ctx->stagedScanLen = -1;
+    leave_batch(ctx);
     return JPEG_HIP_OK;
+}
+
+// Frames and files in host memory.  Passes of a few dozen frames go through two pinned
+// staging blocks and two device blocks: a helper thread packs and uploads pass i + 1 on a
+// second stream while pass i is being encoded, so the GPU only waits for the very first
+// upload.
+extern "C" int jpeg_hip_encode_batch_host(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format, int64_t stride_bytes,
+                                          int64_t image_stride_bytes, int count, const jpeg_hip_params* params,
+                                          uint8_t* h_out, int64_t slot_bytes, int64_t* h_lens) {
+    if (!ctx || !params || !h_rgb || !h_out || !h_lens) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t rowBytes = (int64_t)params->width * 3 * bytes_per_sample(sample_format);
+    const int64_t packedStride = (rowBytes + 3) / 4 * 4;
+    const int64_t packedImage = packedStride * params->height;
+    int64_t maxPass = (192LL << 20) / (packedImage > 0 ? packedImage : 1);   // staging of about 192 MiB per block
+    if (maxPass < 1) maxPass = 1;
+    int pass = 0;
+    // The geometry checks want a pixel pointer; the real (device) one is bound pass by pass.
+    int st = prepare_batch(ctx, h_rgb, sample_format, stride_bytes, image_stride_bytes, count, params, slot_bytes,
+                           (int)(maxPass > (1 << 20) ? (1 << 20) : maxPass), &pass);
+    if (st != JPEG_HIP_OK) return st;
+    if (!ctx->copyStream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copyStream, hipStreamNonBlocking));
+    for (auto& e : ctx->pipeEvent)
+        if (!e) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(ctx, ctx->pipeStage[i].ensure((size_t)(pass * packedImage)));
+        HIP_TRY(ctx, ctx->pipeIn[i].ensure((size_t)(pass * packedImage)));
+    }
+    HIP_TRY(ctx, ctx->pipeOut.ensure((size_t)(pass * slot_bytes)));
+    const int passes = (count + pass - 1) / pass;
+    std::atomic<int> uploaded(0), encoded(0), failed(0);
+    std::thread uploader([&]() {
+        if (hipSetDevice(ctx->device) != hipSuccess) {
+            failed = 1;
+            return;
+        }
+        for (int i = 0; i < passes && !failed; ++i) {
+            while (encoded.load() < i - 1 && !failed) std::this_thread::yield();   // blocks i % 2 are free again
+            const int first = i * pass, n = count - first < pass ? count - first : pass;
+            uint8_t* stage = (uint8_t*)ctx->pipeStage[i & 1].p;
+            for (int k = 0; k < n; ++k) {
+                const uint8_t* src = (const uint8_t*)h_rgb + (int64_t)(first + k) * image_stride_bytes;
+                uint8_t* dst = stage + (int64_t)k * packedImage;
+                if (stride_bytes == packedStride) {
+                    memcpy(dst, src, (size_t)(packedStride * (params->height - 1) + rowBytes));
+                } else {
+                    for (int y = 0; y < params->height; ++y) memcpy(dst + y * packedStride, src + y * stride_bytes, (size_t)rowBytes);
+                }
+            }
+            if (hipMemcpyAsync(ctx->pipeIn[i & 1].p, stage, (size_t)(n * packedImage), hipMemcpyHostToDevice,
+                               ctx->copyStream) != hipSuccess ||
+                hipEventRecord(ctx->pipeEvent[i & 1], ctx->copyStream) != hipSuccess) {
+                failed = 1;
+                return;
+            }
+            uploaded = i + 1;
+        }
+    });
+    for (int i = 0; i < passes && st == JPEG_HIP_OK; ++i) {
+        while (uploaded.load() < i + 1 && !failed) std::this_thread::yield();
+        if (failed) {
+            st = fail(ctx, JPEG_HIP_ERR_HIP, "upload of a pass failed");
+            break;
+        }
+        const int first = i * pass, n = count - first < pass ? count - first : pass;
+        hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->pipeEvent[i & 1], 0);
+        if (e != hipSuccess) {
+            st = hip_fail(ctx, e, "hipStreamWaitEvent");
+            break;
+        }
+        ctx->rgb = ctx->pipeIn[i & 1].p;
+        ctx->stride = packedStride;
+        st = encode_batch_pass(ctx, (const uint8_t*)ctx->pipeIn[i & 1].p, packedImage, n, (uint8_t*)ctx->pipeOut.p, slot_bytes,
+                               h_lens + first);
+        if (st == JPEG_HIP_OK) {
+            int64_t longest = 0;
+            for (int k = 0; k < n; ++k) longest = std::max(longest, h_lens[first + k]);
+            e = hipMemcpy2DAsync(h_out + (int64_t)first * slot_bytes, (size_t)slot_bytes, ctx->pipeOut.p, (size_t)slot_bytes,
+                                 (size_t)longest, (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) st = hip_fail(ctx, e, "download of a pass");
+        }
+        if (st != JPEG_HIP_OK) failed = 1;
+        encoded = i + 1;
+    }
+    failed = failed.load() ? 1 : 0;
+    if (st != JPEG_HIP_OK) failed = 1;   // lets the uploader leave its wait loops
+    uploader.join();
+    (void)hipStreamSynchronize(ctx->copyStream);
+    leave_batch(ctx);
+    return st;
 }
 
 // ---- verification decoder ------------------------------------------------------------------

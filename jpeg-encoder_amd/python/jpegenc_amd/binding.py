@@ -20,7 +20,7 @@ DC, AC = 0, 1
 
 EXPORTS = [
     "jpeg_hip_create", "jpeg_hip_destroy", "jpeg_hip_last_error", "jpeg_hip_status_string", "jpeg_hip_stream",
-    "jpeg_hip_compute_layout", "jpeg_hip_encode", "jpeg_hip_encode_host", "jpeg_hip_encode_batch", "jpeg_hip_begin", "jpeg_hip_upload_pixels",
+    "jpeg_hip_compute_layout", "jpeg_hip_encode", "jpeg_hip_encode_host", "jpeg_hip_encode_batch", "jpeg_hip_encode_batch_host", "jpeg_hip_begin", "jpeg_hip_upload_pixels",
     "jpeg_hip_bind_pixels", "jpeg_hip_transform", "jpeg_hip_histograms", "jpeg_hip_histograms_host",
     "jpeg_hip_huffman_from_histogram", "jpeg_hip_standard_huffman", "jpeg_hip_write_dht", "jpeg_hip_write_headers", "jpeg_hip_set_huffman",
     "jpeg_hip_build_huffman", "jpeg_hip_get_huffman", "jpeg_hip_emit_scan", "jpeg_hip_emit_scan_host",
@@ -87,6 +87,7 @@ def lib():
         L.jpeg_hip_encode.argtypes = [vp, vp, i32, i64, C.POINTER(Params), vp, i64, C.POINTER(i64)]
         L.jpeg_hip_encode_host.argtypes = [vp, vp, i32, i64, C.POINTER(Params), vp, i64, C.POINTER(i64)]
         L.jpeg_hip_encode_batch.argtypes = [vp, vp, i32, i64, i64, i32, C.POINTER(Params), vp, i64, vp]
+        L.jpeg_hip_encode_batch_host.argtypes = [vp, vp, i32, i64, i64, i32, C.POINTER(Params), vp, i64, vp]
         L.jpeg_hip_begin.argtypes = [vp, C.POINTER(Params)]
         L.jpeg_hip_decode_info.argtypes = [vp, i64, C.POINTER(ImageInfo)]
         L.jpeg_hip_decode.argtypes = [vp, vp, i64, vp, i64, i64, C.POINTER(ImageInfo)]
@@ -248,6 +249,17 @@ class Context:
         self._check(lib().jpeg_hip_encode_batch(self._h, C.c_void_p(d_rgb), fmt, stride, image_stride, count,
                                                 C.byref(params), C.c_void_p(d_out), slot_bytes, _np(lens)))
         return lens
+
+    def encode_batch_host(self, frames, params, slot_bytes):
+        """frames: uint8/float32 [N, H, W, 3] on the host -> list of JFIF byte strings."""
+        frames = np.ascontiguousarray(frames)
+        fmt = RGBF32 if frames.dtype == np.float32 else RGB8
+        n = frames.shape[0]
+        out = np.zeros(n * slot_bytes, np.uint8)
+        lens = np.zeros(n, np.int64)
+        self._check(lib().jpeg_hip_encode_batch_host(self._h, _np(frames), fmt, frames.strides[1], frames.strides[0], n,
+                                                     C.byref(params), _np(out), slot_bytes, _np(lens)))
+        return [out[k * slot_bytes:k * slot_bytes + int(lens[k])].tobytes() for k in range(n)]
 
     def encode_host(self, rgb, params, stride=None):
         """rgb: numpy uint8/float32 [H, W, 3] on the host -> JFIF bytes."""

@@ -91,3 +91,45 @@ def test_batch_of_one_and_errors(ctx):
     # the context still works for single images afterwards
     prm = B.make_params(100, 60, T.SCHEME_444, qt)
     assert ctx.encode_host(img, prm) == O.encode(img, T.SCHEME_444, qt).jpeg
+
+
+def test_host_batch_small_frames_and_strides(ctx):
+    w, h, n = 123, 77, 9
+    imgs = [synth.generate("noise" if k % 2 else "natural", w, h, seed=50 + k) for k in range(n)]
+    qt = T.quality_tables(90)
+    prm = B.make_params(w, h, T.SCHEME_420, qt)
+    files = ctx.encode_batch_host(np.stack(imgs), prm, slot_bytes=1 << 16)
+    for k, im in enumerate(imgs):
+        assert files[k] == O.encode(im, T.SCHEME_420, qt).jpeg, k
+    # padded rows and padded images (a view into a larger array)
+    big = np.zeros((n, h + 3, w + 5, 3), np.uint8)
+    big[:, :h, :w] = np.stack(imgs)
+    view = big[:, :h, :w]
+    fmt, out, lens = B.RGB8, np.zeros(n << 16, np.uint8), np.zeros(n, np.int64)
+    import ctypes as C
+    ctx._check(B.lib().jpeg_hip_encode_batch_host(ctx._h, C.c_void_p(view.ctypes.data), fmt, view.strides[1], view.strides[0], n,
+                                                  C.byref(prm), C.c_void_p(out.ctypes.data), 1 << 16,
+                                                  C.c_void_p(lens.ctypes.data)))
+    for k, im in enumerate(imgs):
+        assert out[(k << 16):(k << 16) + int(lens[k])].tobytes() == files[k], k
+    # float frames
+    fl = (np.stack(imgs[:3]).astype(np.float32) / np.float32(255.0))
+    got = ctx.encode_batch_host(fl, prm, slot_bytes=1 << 16)
+    for k in range(3):
+        assert got[k] == O.encode(fl[k], T.SCHEME_420, qt).jpeg, k
+
+
+def test_host_batch_pipelines_several_passes(ctx):
+    # 1080p frames: about 30 fit one staging block, so 70 frames take three passes
+    w, h, n = 1920, 1080, 70
+    base = [synth.generate("natural", w, h, seed=k) for k in range(4)]
+    frames = np.stack([base[k % 4] for k in range(n)])
+    for k in range(n):                                          # make every frame different
+        frames[k, :16, :16, :] = 3 * k
+    qt = T.quality_tables(90)
+    prm = B.make_params(w, h, T.SCHEME_420, qt)
+    files = ctx.encode_batch_host(frames, prm, slot_bytes=1 << 20)
+    for k in (0, 1, 29, 30, 31, 59, 60, 69):
+        assert files[k] == ctx.encode_host(frames[k], prm), k
+    assert files[0] == O.encode(frames[0], T.SCHEME_420, qt).jpeg
+    assert len(set(files)) == n
