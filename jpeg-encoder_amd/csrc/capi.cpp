@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -297,6 +298,8 @@ int64_t coded_bits(const uint64_t* hist, const uint8_t lengths[4][256]) {
 // Waits for the context's stream.  Polls first: a blocking wait costs tens of microseconds
 // to wake up, which is as long as the kernels of a small image take.
 hipError_t wait_stream(jpeg_hip_ctx* ctx) {
+    static const bool blocking = getenv("JPEGENC_BLOCKING_WAIT") != nullptr;
+    if (blocking) return hipStreamSynchronize(ctx->stream);
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         const hipError_t q = hipStreamQuery(ctx->stream);

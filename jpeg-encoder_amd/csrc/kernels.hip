@@ -662,6 +662,23 @@ __device__ __forceinline__ int dc_predictor(const KGeom& g, const int16_t* coef,
     return coef[((m - 1) * g.bpm + last) * 64];
 }
 
+// The same for lanes that hold consecutive blocks (lane l: block b0 + l, DC term in myDc):
+// the predecessor is at most one MCU back, so all but the first lanes of a wave get it from
+// a neighbouring lane instead of from memory.  Call with all lanes of the wave; `active`
+// lanes get a value.
+__device__ __forceinline__ int dc_predictor_lanes(const KGeom& g, const int16_t* coef, long long b, long long m, int k,
+                                                  int c, int myDc, bool active) {
+    const int lane = threadIdx.x & 63;
+    const int first = c == 0 ? 0 : (c == 1 ? g.off1 : g.off2);
+    const int last = (c == 0 ? g.off1 : (c == 1 ? g.off2 : g.bpm)) - 1;
+    const int back = k > first ? 1 : g.bpm - (last - first);   // blocks between this one and its predecessor, 1..bpm
+    const int fromLane = __shfl(myDc, (lane - back) & 63, 64);
+    if (!active) return 0;
+    if (k == first && m % g.mcusPerInterval == 0) return 0;
+    if (lane >= back) return fromLane;
+    return coef[(b - back) * 64];
+}
+
 template <class Visitor>
 __device__ __forceinline__ void walk_block(const u32 (&w)[32], int pred, Visitor& vis) {
     const int diff = coef_at(w, 0) - pred;
@@ -733,7 +750,7 @@ __global__ __launch_bounds__(kEntThreads) void k_histogram(KGeom g, const int16_
         const int c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
         u32 w[32];
         load_block(coef, b, w);
-        const int pred = dc_predictor(g, coef, b, m, k, c);
+        const int pred = dc_predictor_lanes(g, coef, b, m, k, c, coef_at(w, 0), true);
         const int t = c == 0 ? 0 : 1;
         HistVisitor vis{lh + 256 * t, lh + 512 + 256 * t};
         walk_block(w, pred, vis);
@@ -1185,15 +1202,14 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
     __syncthreads();
 
     long long iv = 0;
-    int c = 0, pred = 0;
     bool firstOfInterval = false, lastOfInterval = false;
     PosSummary mine = {0u, 0u};
     u32 bits = 0;
+    const long long m = b / g.bpm;
+    const int k = (int)(b - m * g.bpm);
+    const int c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
+    const int pred = dc_predictor_lanes(g, coef, b, m, k, c, active ? coef_at(w, 0) : 0, active);
     if (active) {
-        const long long m = b / g.bpm;
-        const int k = (int)(b - m * g.bpm);
-        c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
-        pred = dc_predictor(g, coef, b, m, k, c);
         iv = m / g.mcusPerInterval;
         const long long ivFirstBlock = iv * blocksPerInterval;
         long long ivEnd = ivFirstBlock + blocksPerInterval;
