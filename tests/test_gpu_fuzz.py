@@ -1,0 +1,85 @@
+"""Randomised HIP-vs-oracle comparisons: sizes, schemes, tables, restart intervals, content mixes."""
+import numpy as np
+import pytest
+
+import oracle as O
+from jpegenc_amd import binding as B, synth, tables as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = B.Context(0)
+    yield c
+    c.close()
+
+
+def _content(rng, w, h):
+    kind = rng.randint(0, 5)
+    if kind == 0:
+        return synth.generate("natural", w, h, seed=int(rng.randint(1, 1000)))
+    if kind == 1:
+        return synth.generate("noise", w, h, seed=int(rng.randint(1, 1000)))
+    if kind == 2:      # flat with a noisy patch: short and very long blocks side by side
+        img = np.full((h, w, 3), int(rng.randint(0, 256)), np.uint8)
+        y0, x0 = rng.randint(0, h), rng.randint(0, w)
+        img[y0:, x0:] = rng.randint(0, 256, (h - y0, w - x0, 3)).astype(np.uint8)
+        img[y0 + (h - y0) // 4:, :] = img[y0 + (h - y0) // 4:, :] // 64 * 64   # and a posterised part
+        return img
+    if kind == 3:      # extremes: saturated checkerboards
+        yy, xx = np.indices((h, w))
+        v = (((yy // int(rng.randint(1, 4))) + (xx // int(rng.randint(1, 4)))) & 1) * 255
+        return np.stack([v, 255 - v, v], -1).astype(np.uint8)
+    g = np.linspace(0, 255, w)[None, :] * np.ones((h, 1))       # smooth gradient
+    return np.stack([g, g[:, ::-1], g * 0.5], -1).astype(np.uint8)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations_byte_identical(ctx, seed):
+    rng = np.random.RandomState(1000 + seed)
+    names = sorted(T.SCHEMES)
+    for _ in range(6):
+        w, h = int(rng.randint(1, 400)), int(rng.randint(1, 300))
+        scheme = T.SCHEMES[names[rng.randint(len(names))]]
+        img = _content(rng, w, h)
+        which = rng.randint(0, 4)
+        if which == 0:
+            qt = T.quality_tables(int(rng.randint(1, 101)))
+        elif which == 1:
+            qt = T.NAMED_TABLES["ones"]
+        elif which == 2:
+            qt = rng.randint(1, 256, (3, 64)).astype(np.float32)
+        else:
+            qt = T.STANDARD_TABLES
+        mcus = ((w + T.step_size(scheme)[0] - 1) // T.step_size(scheme)[0]) * ((h + T.step_size(scheme)[1] - 1) // T.step_size(scheme)[1])
+        ri = 0 if rng.randint(0, 2) else int(rng.randint(1, max(2, mcus + 2)))
+        pad = bool(rng.randint(0, 2))
+        want = O.encode(img, scheme, qt, restart_interval=ri, pad_ones=pad).jpeg
+        prm = B.make_params(w, h, scheme, qt, restart_interval=ri, pad_ones=pad)
+        got = ctx.encode_host(img, prm)
+        assert got == want, (seed, w, h, ri, pad, which)
+
+
+def test_mostly_flat_image_with_long_blocks(ctx):
+    # Mean block length far below 128 bits (the short-block bit writer is chosen), but a
+    # band of noise at q=100 whose blocks overflow the private words and take the second walk.
+    w, h = 1024, 768
+    img = np.full((h, w, 3), 120, np.uint8)
+    img[300:340, :, :] = synth.generate("noise", w, 40, seed=3)
+    for scheme in ("420", "444"):
+        for ri in (0, 64):
+            qt = T.NAMED_TABLES["ones"]
+            want = O.encode(img, T.SCHEMES[scheme], qt, restart_interval=ri).jpeg
+            got = ctx.encode_host(img, B.make_params(w, h, T.SCHEMES[scheme], qt, restart_interval=ri))
+            assert got == want, (scheme, ri)
+
+
+def test_extreme_aspect_ratios(ctx):
+    qt = T.quality_tables(90)
+    for (w, h) in [(65535, 1), (1, 65535), (65535, 9), (17, 40000)]:
+        img = synth.generate("natural", w, h, seed=2)
+        for scheme in ("420", "444"):
+            want = O.encode(img, T.SCHEMES[scheme], qt).jpeg
+            got = ctx.encode_host(img, B.make_params(w, h, T.SCHEMES[scheme], qt))
+            assert got == want, (w, h, scheme)
