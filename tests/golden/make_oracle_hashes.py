@@ -1,0 +1,55 @@
+"""Writes oracle_hashes.json: SHA-256 of the CPU oracle's output (file bytes, coefficients,
+histograms) for a grid of small configurations.  The hashes pin the oracle against
+accidental changes; they say nothing about the reference (see the oracle's header).
+
+    python tests/golden/make_oracle_hashes.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "jpeg-encoder_amd", "python"))
+import numpy as np  # noqa: E402
+
+import oracle as O  # noqa: E402
+from jpegenc_amd import synth, tables as T  # noqa: E402
+
+SIZES = [(16, 16), (17, 17), (37, 29), (48, 32), (64, 64), (250, 130)]
+SCHEMES = ["444", "422", "420", "411"]
+TABLES = ["annexk", "ps12", "ps5", "ones"]
+
+
+def cases():
+    for (w, h) in SIZES:
+        for scheme in SCHEMES:
+            for tn in TABLES:
+                for kind in ("natural", "noise"):
+                    yield w, h, scheme, tn, kind, 0
+    for ri in (1, 3, 64):
+        yield 123, 77, "420", "annexk", "noise", ri
+
+
+def digest(w, h, scheme, tn, kind, ri):
+    img = synth.generate(kind, w, h, seed=w * 131 + h)
+    enc = O.encode(img, T.SCHEMES[scheme], T.NAMED_TABLES[tn], restart_interval=ri)
+    hs = hashlib.sha256()
+    hs.update(enc.jpeg)
+    for c in range(3):
+        hs.update(np.ascontiguousarray(enc.coef[c]).tobytes())
+    hs.update(np.ascontiguousarray(enc.hist).tobytes())
+    return hs.hexdigest()
+
+
+def main():
+    out = {"%dx%d_%s_%s_%s_ri%d" % c: digest(*c) for c in cases()}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_hashes.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("wrote %d hashes to %s" % (len(out), path))
+
+
+if __name__ == "__main__":
+    main()

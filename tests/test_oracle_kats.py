@@ -148,3 +148,15 @@ def test_division_replacements_are_exact(tmp_path):
     out = subprocess.check_output([exe, "1"], text=True)
     assert "mismatches=0" in out
     assert "hi=0x1.010102p-8 lo=-0x1.fdfdfep-33" in out
+
+
+def test_oracle_output_hashes_unchanged():
+    """The oracle's whole-file output is locked by hashes (tests/golden/make_oracle_hashes.py made them)."""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_oracle_hashes", os.path.join(here, "golden", "make_oracle_hashes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "golden", "oracle_hashes.json")))
+    got = {"%dx%d_%s_%s_%s_ri%d" % c: mod.digest(*c) for c in mod.cases()}
+    assert got == want
