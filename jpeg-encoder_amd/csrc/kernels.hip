@@ -537,7 +537,7 @@ __global__ __launch_bounds__(3 * k444Positions) void k_transform_444(KGeom g, co
     const float m1 = c == 0 ? 0.5870f : (c == 1 ? -0.3312f : -0.4186f);
     const float m2 = c == 0 ? 0.1140f : (c == 1 ? 0.5000f : -0.0813f);
     const float bias = c == 0 ? 0.0f : 0.5f;
-    __shared__ __attribute__((aligned(16))) unsigned char stage[3 * 64 * kStagePitch];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[3 * 32 * kStagePitch];
     const long long m0w = (long long)blockIdx.x * k444Positions;
     const long long m = m0w + (threadIdx.x & 63);
     const long long left = g.nMcu - m0w;
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(3 * k444Positions) void k_transform_444(KGeom g, co
         }
         __builtin_amdgcn_sched_barrier(0);   // row pair by row pair: bounds the live registers
     }
-    finish_block_staged<1>(a, rhi, rlo, stage + c * 64 * kStagePitch, coef + (m0w * 3 + c) * 64, 3, count);
+    finish_block_staged<2>(a, rhi, rlo, stage + c * 32 * kStagePitch, coef + (m0w * 3 + c) * 64, 3, count);
 }
 
 // Pixel filters in front of the transform.  One thread per pixel; in place when src == dst.
