@@ -133,3 +133,25 @@ def test_host_batch_pipelines_several_passes(ctx):
         assert files[k] == ctx.encode_host(frames[k], prm), k
     assert files[0] == O.encode(frames[0], T.SCHEME_420, qt).jpeg
     assert len(set(files)) == n
+
+
+def test_device_batch_split_into_passes(ctx):
+    # 70 frames of 3840x2160 4:2:0 are 13.6 M blocks: more than one pass of the batch entry point
+    import torch
+    from jpegenc_amd import synth_torch
+    w, h, n = 3840, 2160, 70
+    base = synth_torch.generate("natural", w, h, device="cuda")
+    frames = base.reshape(1, h, w, 3).repeat(n, 1, 1, 1).contiguous()
+    for k in range(n):
+        frames[k, 8 * (k % 200):8 * (k % 200) + 64, :256, :] = (3 * k) & 255
+    qt = T.quality_tables(90)
+    for std in (False, True):
+        prm = B.make_params(w, h, T.SCHEME_420, qt, standard_huffman=std)
+        slot = 4 << 20
+        out = torch.zeros(n * slot, dtype=torch.uint8, device="cuda")
+        lens = ctx.encode_batch(frames.data_ptr(), B.RGB8, w * 3, w * h * 3, n, prm, out.data_ptr(), slot)
+        one = torch.zeros(slot, dtype=torch.uint8, device="cuda")
+        for k in (0, 1, 33, 66, 67, 68, 69):
+            m = ctx.encode(frames[k].data_ptr(), B.RGB8, w * 3, prm, one.data_ptr(), slot)
+            assert m == int(lens[k]), (std, k)
+            assert torch.equal(one[:m], out[k * slot:k * slot + m]), (std, k)
