@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--band-of", type=int, default=0,
                     help="diagnostic: encode only rank 0's band of an image sharded over this many ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--analyze-only", action="store_true",
+                    help="diagnostic: stop after the transform and the histogram pass (no file is written)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,6 +160,8 @@ def main():
             lens = ctx.encode_batch(rgb.data_ptr(), B.RGB8, stride, image_stride, batch, params, out.data_ptr(), cap)
             return int(lens.sum())
         ctx.analyze_band(rgb.data_ptr(), B.RGB8, stride, params, hist.data_ptr())
+        if args.analyze_only:
+            return 0
         if world > 1 and not args.standard_huffman:
             cur = torch.cuda.current_stream()
             cur.wait_stream(ext)

@@ -651,32 +651,48 @@ __device__ __forceinline__ int coef_at(const u32 (&w)[32], int i) {
     return (int)(short)(w[i >> 1] >> ((i & 1) * 16));
 }
 
-// DC predictor of block b: the previous block of the same channel in scan order, 0 at
-// the start of a restart interval (and of the band).
-__device__ __forceinline__ int dc_predictor(const KGeom& g, const int16_t* coef, long long b, long long m, int k,
-                                            int c) {
-    const int first = c == 0 ? 0 : (c == 1 ? g.off1 : g.off2);
-    if (k > first) return coef[(b - 1) * 64];
-    if (m % g.mcusPerInterval == 0) return 0;
-    const int last = (c == 0 ? g.off1 : (c == 1 ? g.off2 : g.bpm)) - 1;
-    return coef[((m - 1) * g.bpm + last) * 64];
+// Where a block sits in its image.  The block index inside one image fits 32 bits for every
+// legal JPEG (65535 x 65535 pixels are 2 * 10^8 blocks), which keeps the divisions cheap.
+struct BlockRole {
+    u32 mcu;       // MCU inside the image
+    int k;         // block inside the MCU
+    int c;         // channel
+    int back;      // blocks between this one and the previous block of its channel, 1..bpm
+    bool resets;   // first block of its channel in a restart interval: the DC predictor is 0
+};
+
+__device__ __forceinline__ BlockRole block_role(const KGeom& g, u32 bl) {
+    BlockRole r;
+    const u32 bpm = (u32)g.bpm;
+    r.mcu = bl / bpm;
+    r.k = (int)(bl - r.mcu * bpm);
+    r.c = r.k < g.off1 ? 0 : (r.k < g.off2 ? 1 : 2);
+    const int first = r.c == 0 ? 0 : (r.c == 1 ? g.off1 : g.off2);
+    const int last = (r.c == 0 ? g.off1 : (r.c == 1 ? g.off2 : g.bpm)) - 1;
+    r.back = r.k > first ? 1 : g.bpm - (last - first);
+    // One interval per image (no restarts, or a batch): only MCU 0 starts one.
+    const bool atStart = g.intervals == g.batch ? r.mcu == 0 : r.mcu % (u32)g.mcusPerInterval == 0;
+    r.resets = r.k == first && atStart;
+    return r;
 }
 
-// The same for lanes that hold consecutive blocks (lane l: block b0 + l, DC term in myDc):
-// the predecessor is at most one MCU back, so all but the first lanes of a wave get it from
-// a neighbouring lane instead of from memory.  Call with all lanes of the wave; `active`
-// lanes get a value.
-__device__ __forceinline__ int dc_predictor_lanes(const KGeom& g, const int16_t* coef, long long b, long long m, int k,
-                                                  int c, int myDc, bool active) {
+// Block whose DC term the lane has to fetch from memory as predictor of block b: lanes hold
+// consecutive blocks (lane l: block b0 + l), the predecessor is at most one MCU back, so all
+// but the first `back` lanes of a wave get it from a neighbouring lane.  Lanes that need no
+// fetch name their own block, which keeps the address valid and the line in cache.
+__device__ __forceinline__ long long dc_predictor_source(const BlockRole& r, long long b) {
     const int lane = threadIdx.x & 63;
-    const int first = c == 0 ? 0 : (c == 1 ? g.off1 : g.off2);
-    const int last = (c == 0 ? g.off1 : (c == 1 ? g.off2 : g.bpm)) - 1;
-    const int back = k > first ? 1 : g.bpm - (last - first);   // blocks between this one and its predecessor, 1..bpm
-    const int fromLane = __shfl(myDc, (lane - back) & 63, 64);
-    if (!active) return 0;
-    if (k == first && m % g.mcusPerInterval == 0) return 0;
-    if (lane >= back) return fromLane;
-    return coef[(b - back) * 64];
+    return (lane >= r.back || r.resets) ? b : b - r.back;
+}
+
+// DC predictor (previous block of the same channel in scan order, 0 at the start of a
+// restart interval and of the band) from the lane's own DC term, its neighbours' and the
+// term fetched from dc_predictor_source().  Call with all lanes of the wave.
+__device__ __forceinline__ int dc_predictor_lanes(const BlockRole& r, int myDc, int fetchedDc, bool active) {
+    const int lane = threadIdx.x & 63;
+    const int fromLane = __shfl(myDc, (lane - r.back) & 63, 64);
+    if (!active || r.resets) return 0;
+    return lane >= r.back ? fromLane : fetchedDc;
 }
 
 template <class Visitor>
@@ -741,19 +757,22 @@ __global__ __launch_bounds__(kEntThreads) void k_histogram(KGeom g, const int16_
     __shared__ u32 lh[4 * 256];   // DC-Y, DC-C, AC-Y, AC-C (Encoder.cpp:368-416)
     for (int i = threadIdx.x; i < 1024; i += kEntThreads) lh[i] = 0;
     __syncthreads();
-    const long long first = (long long)blockIdx.y * g.blocksPerImage;
-    for (long long bl = (long long)blockIdx.x * kEntThreads + threadIdx.x; bl < g.blocksPerImage;
-         bl += (long long)gridDim.x * kEntThreads) {
-        const long long b = first + bl;
-        const long long m = b / g.bpm;
-        const int k = (int)(b - m * g.bpm);
-        const int c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
+    const int16_t* image = coef + (long long)blockIdx.y * g.blocksPerImage * 64;
+    const u32 blocks = (u32)g.blocksPerImage;
+    const u32 stride = gridDim.x * kEntThreads;
+    for (u32 bl = blockIdx.x * kEntThreads + threadIdx.x; __any(bl < blocks); bl += stride) {
+        const bool active = bl < blocks;
+        const u32 cur = active ? bl : blocks - 1;   // lanes past the end stay in step for the shuffle
+        const BlockRole role = block_role(g, cur);
         u32 w[32];
-        load_block(coef, b, w);
-        const int pred = dc_predictor_lanes(g, coef, b, m, k, c, coef_at(w, 0), true);
-        const int t = c == 0 ? 0 : 1;
-        HistVisitor vis{lh + 256 * t, lh + 512 + 256 * t};
-        walk_block(w, pred, vis);
+        load_block(image, cur, w);
+        const int fetched = image[dc_predictor_source(role, cur) * 64];
+        const int pred = dc_predictor_lanes(role, coef_at(w, 0), fetched, active);
+        if (active) {
+            const int t = role.c == 0 ? 0 : 1;
+            HistVisitor vis{lh + 256 * t, lh + 512 + 256 * t};
+            walk_block(w, pred, vis);
+        }
     }
     __syncthreads();
     u64* mine = hist + (long long)blockIdx.y * 1024;
@@ -1187,16 +1206,23 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
     u64* counter = state + tiles;
     if (threadIdx.x == 0) tileNo = (long long)atomicAdd((unsigned long long*)counter, 1ull);
     __syncthreads();
-    const long long tile = tileNo;
-    const long long image = tile / tilesPerImage;
-    const long long bl = (tile - image * tilesPerImage) * kEntThreads + threadIdx.x;
-    const long long b = image * g.blocksPerImage + bl;
-    const bool active = bl < g.blocksPerImage;
+    // Tile and block numbers fit 32 bits (see BlockRole); the tile number is the same for
+    // the whole workgroup.
+    const u32 tile = __builtin_amdgcn_readfirstlane((u32)tileNo);
+    const u32 image = g.batch > 1 ? tile / (u32)tilesPerImage : 0u;
+    const u32 bl = (tile - image * (u32)tilesPerImage) * kEntThreads + threadIdx.x;
+    const long long b = (long long)image * g.blocksPerImage + bl;
+    const bool active = bl < (u32)g.blocksPerImage;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long blocksPerInterval = g.mcusPerInterval * g.bpm;
+    const BlockRole role = block_role(g, active ? bl : (u32)g.blocksPerImage - 1);
 
     u32 w[32];
-    if (active) load_block(coef, b, w);   // in flight while the tables are staged
+    int fetchedDc = 0;
+    if (active) {   // in flight while the tables are staged
+        load_block(coef, b, w);
+        fetchedDc = coef[dc_predictor_source(role, b) * 64];
+    }
     const u32* myTables = tables + image * g.tableStride;
     for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = myTables[i];
     __syncthreads();
@@ -1205,12 +1231,10 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
     bool firstOfInterval = false, lastOfInterval = false;
     PosSummary mine = {0u, 0u};
     u32 bits = 0;
-    const long long m = b / g.bpm;
-    const int k = (int)(b - m * g.bpm);
-    const int c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
-    const int pred = dc_predictor_lanes(g, coef, b, m, k, c, active ? coef_at(w, 0) : 0, active);
+    const int c = role.c;
+    const int pred = dc_predictor_lanes(role, active ? coef_at(w, 0) : 0, fetchedDc, active);
     if (active) {
-        iv = m / g.mcusPerInterval;
+        iv = g.intervals == g.batch ? (long long)image : (long long)(role.mcu / (u32)g.mcusPerInterval);
         const long long ivFirstBlock = iv * blocksPerInterval;
         long long ivEnd = ivFirstBlock + blocksPerInterval;
         if (ivEnd > g.totalBlocks) ivEnd = g.totalBlocks;
