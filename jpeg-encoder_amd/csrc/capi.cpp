@@ -9,6 +9,9 @@
 #include <new>
 #include <string>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -146,7 +149,83 @@ struct Pinned {
     uint64_t result[4];
 };
 
+// Host threads that stay around between batch passes: starting sixteen threads costs more
+// than the table work they are started for.
+class WorkerPool {
+public:
+    explicit WorkerPool(int threads) {
+        for (int i = 0; i < threads; ++i) threads_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            stop_ = true;
+            stopFlag_.store(true);
+        }
+        wake_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    int size() const { return (int)threads_.size(); }
+    // Calls fn(i) for every i in [0, n), on the pool's threads and the caller's, and returns
+    // when all calls have returned.  One run at a time.
+    void run(int n, const std::function<void(int)>& fn) {
+        bool asleep;
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            fn_ = &fn;
+            n_ = n;
+            next_.store(0);
+            busy_.store((int)threads_.size());
+            asleep = sleepers_ > 0;
+            generation_.fetch_add(1);
+        }
+        if (asleep) wake_.notify_all();
+        for (int i; (i = next_.fetch_add(1)) < n;) fn(i);
+        while (busy_.load() != 0) std::this_thread::yield();
+        fn_ = nullptr;
+    }
+
+private:
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            // Runs of one batch pass follow each other within a fraction of a millisecond, and
+            // waking a sleeping thread takes about as long as its share of a run: stay awake
+            // for a while after a run before going to sleep.
+            const auto idleSince = std::chrono::steady_clock::now();
+            while (generation_.load() == seen && !stopFlag_.load() &&
+                   std::chrono::steady_clock::now() - idleSince < std::chrono::microseconds(500))
+                std::this_thread::yield();
+            const std::function<void(int)>* fn;
+            int n;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                ++sleepers_;
+                wake_.wait(lock, [&] { return stop_ || generation_.load() != seen; });
+                --sleepers_;
+                if (stop_) return;
+                seen = generation_.load();
+                fn = fn_;
+                n = n_;
+            }
+            for (int i; (i = next_.fetch_add(1)) < n;) (*fn)(i);
+            busy_.fetch_sub(1);
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable wake_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int n_ = 0, sleepers_ = 0;
+    std::atomic<int> next_{0}, busy_{0};
+    std::atomic<uint64_t> generation_{0};
+    std::atomic<bool> stopFlag_{false};
+    bool stop_ = false;
+};
+
 }  // namespace
+
+constexpr int kBatchParts = 8;   // pieces a batch pass is cut into to hide the host's table building
 
 struct jpeg_hip_ctx {
     int device = 0;
@@ -164,9 +243,16 @@ struct jpeg_hip_ctx {
     DevBuf pixels, coef, qtab, hist, tables, ivOff, ffCount, ffOff, scanTmp, result, unstuffed,
         staging, batchHdr, batchHdrLen, batchFfStart, tileState, decCoef, decPlanes, decTables, decRgb, decSum, pixelsF, pipeIn[2], pipeOut;
     jpeghip::DecodedStream* decoded = nullptr;   // last file given to the verification decoder
+    WorkerPool* workers = nullptr;               // created by the first batch pass
     HostBuf hostHist, hostTables, hostHdr, hostHdrLen, hostOffsets, pipeStage[2];
     hipStream_t copyStream = nullptr;
     hipEvent_t pipeEvent[2] = {nullptr, nullptr};
+    hipStream_t histStream = nullptr;            // carries a batch pass's histograms to the host
+    hipStream_t tableStream = nullptr;           // ... and its tables and headers to the device
+    hipEvent_t partCounted[kBatchParts] = {};    // a part of a batch pass has its histograms
+    hipEvent_t partEvent[kBatchParts] = {};      // ... and they are on the host
+    hipEvent_t partTime[kBatchParts][4] = {};    // profiling: around the part's transform, around its histogram pass
+    bool partTimed[kBatchParts] = {};            // the part started a transform launch in the current pass
     EntropyWorkspace ws;
     Pinned* pin = nullptr;
     uint8_t lengths[4][256];
@@ -305,6 +391,18 @@ hipError_t wait_stream(jpeg_hip_ctx* ctx) {
         const hipError_t q = hipStreamQuery(ctx->stream);
         if (q != hipErrorNotReady) return q;
         if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipStreamSynchronize(ctx->stream);
+    }
+}
+
+// The same for an event recorded on the stream.
+hipError_t wait_event(hipEvent_t ev) {
+    static const bool blocking = getenv("JPEGENC_BLOCKING_WAIT") != nullptr;
+    if (blocking) return hipEventSynchronize(ev);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q != hipErrorNotReady) return q;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipEventSynchronize(ev);
     }
 }
 
@@ -472,11 +570,21 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
                       &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum, &ctx->pixelsF, &ctx->pipeIn[0], &ctx->pipeIn[1],
                       &ctx->pipeOut};
     delete ctx->decoded;
+    delete ctx->workers;
     for (DevBuf* b : bufs) b->release();
     HostBuf* hbufs[] = {&ctx->hostHist, &ctx->hostTables, &ctx->hostHdr, &ctx->hostHdrLen, &ctx->hostOffsets,
                         &ctx->pipeStage[0], &ctx->pipeStage[1]};
     for (auto& e : ctx->pipeEvent)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->partEvent)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->partCounted)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& part : ctx->partTime)
+        for (auto& e : part)
+            if (e) (void)hipEventDestroy(e);
+    if (ctx->histStream) (void)hipStreamDestroy(ctx->histStream);
+    if (ctx->tableStream) (void)hipStreamDestroy(ctx->tableStream);
     if (ctx->copyStream) (void)hipStreamDestroy(ctx->copyStream);
     for (HostBuf* b : hbufs) b->release();
     for (auto& e : ctx->ev)
@@ -870,13 +978,14 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     k.intervals = n;
     k.firstInterval = 0;
     k.writeEoi = 1;
-    mark(ctx, 0);
-    HIP_TRY(ctx, launch_transform(k, d_rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, ctx->stream));
-    mark(ctx, 1);
     const bool standard = ctx->prm.standard_huffman != 0;
     int64_t totalBits = 0;
+    int parts = 1;
     if (standard) {
         // One table set and one header serve every image; nothing waits for the host.
+        mark(ctx, 0);
+        HIP_TRY(ctx, launch_transform(k, d_rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, ctx->stream));
+        mark(ctx, 1);
         mark(ctx, 2);
         k.tableStride = 0;
         uint8_t lengths[4][256];
@@ -895,39 +1004,103 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
         }
         totalBits = -1;
     } else {
-    HIP_TRY(ctx, launch_histogram(k, (const int16_t*)ctx->coef.p, (unsigned long long*)ctx->hist.p, ctx->stream));
-    mark(ctx, 2);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->hostHist.p, ctx->hist.p, (size_t)n * 1024 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, wait_stream(ctx));
-
-    auto t0 = std::chrono::steady_clock::now();
-    unsigned hw = std::thread::hardware_concurrency();
-    int workers = (int)(hw == 0 ? 1 : (hw > 16 ? 16 : hw));
-    if (workers > (n + 3) / 4) workers = (n + 3) / 4;
-    std::vector<int> status((size_t)workers, JPEG_HIP_OK);
-    std::vector<int64_t> bits((size_t)workers, 0);
-    std::vector<std::thread> pool;
-    const int per = (n + workers - 1) / workers;
-    for (int w = 1; w < workers; ++w) {
-        const int a = w * per, b = a + per < n ? a + per : n;
-        if (a >= b) break;
-        pool.emplace_back(batch_tables_worker, ctx, a, b, (const uint64_t*)ctx->hostHist.p, (uint32_t*)ctx->hostTables.p,
-                          (uint8_t*)ctx->hostHdr.p, (uint32_t*)ctx->hostHdrLen.p, &status[(size_t)w], &bits[(size_t)w]);
+    // The histogram pass runs in up to eight parts, each followed (on a stream of its own, so
+    // that the parts stay back to back) by the copy of its histograms: the host builds the
+    // tables of one part, and sends them back on a third stream, while the device works on
+    // the next ones.  Sixteen host threads need about as long for the tables of a pass as
+    // the device for its histograms.
+    if (!ctx->histStream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->histStream, hipStreamNonBlocking));
+    if (!ctx->tableStream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->tableStream, hipStreamNonBlocking));
+    parts = n / 16 < 1 ? 1 : (n / 16 > kBatchParts ? kBatchParts : n / 16);
+    // The transform runs in two launches: one would let the host start later, one per part
+    // costs the transform a tenth of its speed.
+    const int groups = parts >= 4 ? 2 : 1;
+    int partBegin[kBatchParts + 1];
+    for (int p = 0; p <= parts; ++p) partBegin[p] = (int)((int64_t)n * p / parts);
+    HIP_TRY(ctx, launch_clear_histograms((unsigned long long*)ctx->hist.p, n, ctx->stream));
+    auto part_geometry = [&](int a, int cnt) {
+        KGeom kp = k;
+        kp.batch = cnt;
+        kp.intervals = cnt;
+        kp.nMcu = g.nMcu * cnt;
+        kp.totalBlocks = g.totalBlocks * cnt;
+        return kp;
+    };
+    for (int grp = 0; grp < groups; ++grp) {
+        const int p0 = parts * grp / groups, p1 = parts * (grp + 1) / groups;
+        const int ga = partBegin[p0], gcnt = partBegin[p1] - ga;
+        if (ctx->profiling) {
+            for (int p = p0; p < p1; ++p)
+                for (auto& e : ctx->partTime[p])
+                    if (!e) HIP_TRY(ctx, hipEventCreate(&e));
+            HIP_TRY(ctx, hipEventRecord(ctx->partTime[p0][0], ctx->stream));
+        }
+        for (int p = p0; p < p1; ++p) ctx->partTimed[p] = p == p0;
+        HIP_TRY(ctx, launch_transform(part_geometry(ga, gcnt), d_rgb + (int64_t)ga * imageStride, (const float*)ctx->qtab.p,
+                                      (int16_t*)ctx->coef.p + (int64_t)ga * g.totalBlocks * 64, ctx->stream));
+        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->partTime[p0][1], ctx->stream));
+        for (int p = p0; p < p1; ++p) {
+            const int a = partBegin[p], cnt = partBegin[p + 1] - a;
+            if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->partTime[p][2], ctx->stream));
+            HIP_TRY(ctx, launch_histogram(part_geometry(a, cnt), (const int16_t*)ctx->coef.p + (int64_t)a * g.totalBlocks * 64,
+                                          (unsigned long long*)ctx->hist.p + (size_t)a * 1024, ctx->stream, false));
+            if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->partTime[p][3], ctx->stream));
+            if (!ctx->partCounted[p]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->partCounted[p], hipEventDisableTiming));
+            if (!ctx->partEvent[p]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->partEvent[p], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventRecord(ctx->partCounted[p], ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->histStream, ctx->partCounted[p], 0));
+            HIP_TRY(ctx, hipMemcpyAsync((uint64_t*)ctx->hostHist.p + (size_t)a * 1024, (const uint64_t*)ctx->hist.p + (size_t)a * 1024,
+                                        (size_t)cnt * 1024 * 8, hipMemcpyDeviceToHost, ctx->histStream));
+            HIP_TRY(ctx, hipEventRecord(ctx->partEvent[p], ctx->histStream));
+        }
     }
-    batch_tables_worker(ctx, 0, per < n ? per : n, (const uint64_t*)ctx->hostHist.p, (uint32_t*)ctx->hostTables.p,
-                        (uint8_t*)ctx->hostHdr.p, (uint32_t*)ctx->hostHdrLen.p, &status[0], &bits[0]);
-    for (auto& t : pool) t.join();
+    if (!ctx->workers) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        ctx->workers = new WorkerPool((int)(hw == 0 ? 1 : (hw > 16 ? 16 : hw)) - 1);
+    }
+    // Two images per task: enough tasks to balance the threads, few enough to keep the
+    // claim counter quiet.
+    const int per = 2, tasks = (n + per - 1) / per + parts;
+    std::vector<int> status((size_t)tasks, JPEG_HIP_OK);
+    std::vector<int64_t> bits((size_t)tasks, 0);
+    int taskBase = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int p = 0; p < parts; ++p) {
+        HIP_TRY(ctx, wait_event(ctx->partEvent[p]));
+        if (p == parts - 1) t0 = std::chrono::steady_clock::now();   // what follows is no longer hidden behind the device
+        const int a0 = partBegin[p], a1 = partBegin[p + 1];
+        const int partTasks = (a1 - a0 + per - 1) / per;
+        ctx->workers->run(partTasks, [&](int t) {
+            const int a = a0 + t * per, b = a + per < a1 ? a + per : a1;
+            batch_tables_worker(ctx, a, b, (const uint64_t*)ctx->hostHist.p, (uint32_t*)ctx->hostTables.p,
+                                (uint8_t*)ctx->hostHdr.p, (uint32_t*)ctx->hostHdrLen.p, &status[(size_t)(taskBase + t)],
+                                &bits[(size_t)(taskBase + t)]);
+        });
+        taskBase += partTasks;
+        // The part's tables and headers travel while the device is still busy with later parts.
+        const size_t cnt = (size_t)(a1 - a0);
+        HIP_TRY(ctx, hipMemcpyAsync((uint32_t*)ctx->tables.p + (size_t)a0 * 1024, (const uint32_t*)ctx->hostTables.p + (size_t)a0 * 1024,
+                                    cnt * 1024 * 4, hipMemcpyHostToDevice, ctx->tableStream));
+        HIP_TRY(ctx, hipMemcpyAsync((uint8_t*)ctx->batchHdr.p + (size_t)a0 * kBatchHeaderPitch,
+                                    (const uint8_t*)ctx->hostHdr.p + (size_t)a0 * kBatchHeaderPitch, cnt * kBatchHeaderPitch,
+                                    hipMemcpyHostToDevice, ctx->tableStream));
+        HIP_TRY(ctx, hipMemcpyAsync((uint32_t*)ctx->batchHdrLen.p + a0, (const uint32_t*)ctx->hostHdrLen.p + a0, cnt * 4,
+                                    hipMemcpyHostToDevice, ctx->tableStream));
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->partCounted[0], ctx->tableStream));   // free again: its part was counted long ago
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->partCounted[0], 0));
     for (int st : status)
         if (st != JPEG_HIP_OK) return fail(ctx, st, "Huffman tables or headers of a batch image could not be built");
     ctx->times[3] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (int64_t v : bits) totalBits += v;
     }
 
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->hostTables.p, (size_t)(standard ? 1 : n) * 1024 * 4, hipMemcpyHostToDevice,
-                                ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->batchHdr.p, ctx->hostHdr.p, (size_t)n * kBatchHeaderPitch, hipMemcpyHostToDevice,
-                                ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->batchHdrLen.p, ctx->hostHdrLen.p, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (standard) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->hostTables.p, 1024 * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->batchHdr.p, ctx->hostHdr.p, (size_t)n * kBatchHeaderPitch, hipMemcpyHostToDevice,
+                                    ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->batchHdrLen.p, ctx->hostHdrLen.p, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     BatchOutput bo;
     bo.out = d_out;
     bo.slotBytes = slotBytes;
@@ -948,8 +1121,17 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     HIP_TRY(ctx, wait_stream(ctx));
     if (ctx->profiling) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->times[0] += ms;
-        if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->times[1] += ms;
+        if (standard) {
+            if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->times[0] += ms;
+        } else {
+            // A part that did not start a transform launch left its first two events
+            // unrecorded in this pass; those report an error or a stale pair, both skipped.
+            for (int p = 0; p < parts; ++p) {
+                if (ctx->partTimed[p] && hipEventElapsedTime(&ms, ctx->partTime[p][0], ctx->partTime[p][1]) == hipSuccess)
+                    ctx->times[0] += ms;
+                if (hipEventElapsedTime(&ms, ctx->partTime[p][2], ctx->partTime[p][3]) == hipSuccess) ctx->times[1] += ms;
+            }
+        }
         if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->times[2] += ms;
     }
     if (off[2 * (n + 1) + 1] & 2) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer's tiles lost their chain");

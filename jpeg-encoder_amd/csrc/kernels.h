@@ -76,8 +76,11 @@ hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qt
 hipError_t launch_pixel_filter(const void* d_src, int sampleFormat, long long srcStride, float* d_dst, int width, int rows,
                                int filter, int channel, float value, hipStream_t s);
 
-// Symbol histograms (uint64[4][256] per image of the batch); d_hist is cleared first.
-hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, unsigned long long* d_hist, hipStream_t s);
+// Symbol histograms (uint64[4][256] per image of the batch); d_hist is cleared first unless
+// the caller has done that (launch_clear_histograms) for several launches at once.
+hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, unsigned long long* d_hist, hipStream_t s,
+                            bool clear = true);
+hipError_t launch_clear_histograms(unsigned long long* d_hist, int images, hipStream_t s);
 
 // Single-pass bit writer (lengths, positions, bits) and byte stuffing.  d_tables:
 // uint32[4][256], entry = (length << 16) | code.  Scan bytes go to d_out + prefixLen; EOI is appended when

@@ -786,10 +786,18 @@ __global__ __launch_bounds__(256) void k_zero_words(u64* __restrict__ p, long lo
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0;
 }
 
-hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s) {
-    const long long words = 1024LL * g.batch;
+hipError_t launch_clear_histograms(unsigned long long* d_hist, int images, hipStream_t s) {
+    const long long words = 1024LL * images;
     hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((words + 255) / 256 > 1024 ? 1024 : (words + 255) / 256)), dim3(256), 0,
                        s, d_hist, words);
+    return hipGetLastError();
+}
+
+hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, bool clear) {
+    if (clear) {
+        const hipError_t e = launch_clear_histograms(d_hist, g.batch, s);
+        if (e != hipSuccess) return e;
+    }
     // Every workgroup takes the same number of 256-block passes.
     const long long passes = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
     const long long cap = g.batch > 1 ? (4096 / g.batch > 8 ? 4096 / g.batch : 8) : 2048;
