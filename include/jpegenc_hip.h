@@ -169,6 +169,15 @@ int jpeg_hip_bind_pixels(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format
  * what the next jpeg_hip_transform reads.  channel: 0 R, 1 G, 2 B (ignored for sepia). */
 enum { JPEG_HIP_FILTER_SEPIA = 0, JPEG_HIP_FILTER_MULTIPLY = 1 };
 int jpeg_hip_filter_pixels(jpeg_hip_ctx* ctx, int filter, int channel, float value);
+/* Encoder::multiplyColorChannelBy called after convertToYCbCr (Encoder.cpp:35-38, multiplyAVX,
+ * SIMD256.h:246-258): the next jpeg_hip_transform multiplies every sample of component
+ * `channel` (0 Y, 1 Cb, 2 Cr) by `value`, before the resolution is reduced
+ * (after_subsampling = 0: the call came between convertToYCbCr and
+ * reduceResolutionBySchema) or after it (1).  Up to JPEG_HIP_MAX_GAINS calls, applied in
+ * call order; jpeg_hip_begin forgets them.  One-call entry points (encode, batch, bands)
+ * do not take gains. */
+enum { JPEG_HIP_MAX_GAINS = 4 };
+int jpeg_hip_channel_gain(jpeg_hip_ctx* ctx, int channel, float value, int after_subsampling);
 /* The context's current pixels as floats on the host (three per pixel, rows of the band),
  * e.g. to look at a filter's result the way ImageLoader::SavePPM would. */
 int jpeg_hip_get_pixels(jpeg_hip_ctx* ctx, float* h_rgb, int64_t capacity_floats);

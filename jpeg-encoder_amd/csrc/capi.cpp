@@ -244,6 +244,11 @@ struct jpeg_hip_ctx {
         staging, batchHdr, batchHdrLen, batchFfStart, tileState, decCoef, decPlanes, decTables, decRgb, decSum, pixelsF, pipeIn[2], pipeOut;
     jpeghip::DecodedStream* decoded = nullptr;   // last file given to the verification decoder
     WorkerPool* workers = nullptr;               // created by the first batch pass
+    int nGains = 0;                              // jpeg_hip_channel_gain calls since begin()
+    struct {
+        int channel, afterSubsampling;
+        float value;
+    } gains[JPEG_HIP_MAX_GAINS];
     HostBuf hostHist, hostTables, hostHdr, hostHdrLen, hostOffsets, pipeStage[2];
     hipStream_t copyStream = nullptr;
     hipEvent_t pipeEvent[2] = {nullptr, nullptr};
@@ -328,6 +333,7 @@ void fill_kgeom(jpeg_hip_ctx* ctx) {
     k.blocksPerImage = g.totalBlocks;
     k.imageStrideBytes = 0;
     k.tableStride = 1024;
+    k.nGains = 0;
 }
 
 // Workspace for `images` images of the current geometry (1 outside batch mode; in a batch
@@ -490,7 +496,8 @@ int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capac
     return JPEG_HIP_OK;
 }
 
-int do_transform(jpeg_hip_ctx* ctx, int stages) {
+// staged: the call comes from jpeg_hip_transform, which honours jpeg_hip_channel_gain.
+int do_transform(jpeg_hip_ctx* ctx, int stages, bool staged = false) {
     if (!ctx->begun || !ctx->hasPixels) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "transform needs begin() and pixels");
     const Geometry& g = ctx->geo;
     const bool subsampled = g.blocksPerMcu != 3;
@@ -498,6 +505,14 @@ int do_transform(jpeg_hip_ctx* ctx, int stages) {
         return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "a subsampled scheme needs the subsample stage");
     fill_kgeom(ctx);
     ctx->kg.stages = stages;
+    if (staged) {
+        ctx->kg.nGains = ctx->nGains;
+        for (int i = 0; i < ctx->nGains; ++i) {
+            ctx->kg.gains[i].channel = ctx->gains[i].channel;
+            ctx->kg.gains[i].afterSubsampling = ctx->gains[i].afterSubsampling;
+            ctx->kg.gains[i].value = ctx->gains[i].value;
+        }
+    }
     mark(ctx, 0);
     HIP_TRY(ctx, launch_transform(ctx->kg, ctx->rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, ctx->stream));
     mark(ctx, 1);
@@ -633,6 +648,7 @@ int jpeg_hip_begin(jpeg_hip_ctx* ctx, const jpeg_hip_params* params) {
     ctx->geo = g;
     ctx->begun = true;
     ctx->hasPixels = ctx->transformed = ctx->hasTables = false;
+    ctx->nGains = 0;
     const int ws = ensure_workspace(ctx);
     if (ws != JPEG_HIP_OK) return ws;
     // The divisors stay on the device from one image to the next while they do not change.
@@ -710,6 +726,21 @@ int jpeg_hip_filter_pixels(jpeg_hip_ctx* ctx, int filter, int channel, float val
     return JPEG_HIP_OK;
 }
 
+int jpeg_hip_channel_gain(jpeg_hip_ctx* ctx, int channel, float value, int after_subsampling) {
+    if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "channel gains need begin()");
+    if (channel < 0 || channel > 2) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "unknown channel");
+    if (ctx->prm.standard_huffman)
+        return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "the standard Huffman tables cover 8-bit pixels only");
+    if (ctx->nGains >= JPEG_HIP_MAX_GAINS) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "too many channel gains");
+    ctx->gains[ctx->nGains].channel = channel;
+    ctx->gains[ctx->nGains].afterSubsampling = after_subsampling ? 1 : 0;
+    ctx->gains[ctx->nGains].value = value;
+    ++ctx->nGains;
+    ctx->transformed = false;
+    return JPEG_HIP_OK;
+}
+
 int jpeg_hip_get_pixels(jpeg_hip_ctx* ctx, float* h_rgb, int64_t capacity_floats) {
     if (!ctx || !h_rgb) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (!ctx->begun || !ctx->hasPixels) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "no pixels");
@@ -730,7 +761,7 @@ int jpeg_hip_get_pixels(jpeg_hip_ctx* ctx, float* h_rgb, int64_t capacity_floats
 int jpeg_hip_transform(jpeg_hip_ctx* ctx, int stages) {
     if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    return do_transform(ctx, stages);
+    return do_transform(ctx, stages, true);
 }
 
 int jpeg_hip_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist) {

@@ -35,6 +35,13 @@ struct KGeom {
     long long blocksPerImage;
     long long imageStrideBytes;
     int tableStride;             // entries between the Huffman table sets of consecutive images (0: one shared set)
+    // Encoder::multiplyColorChannelBy calls made after convertToYCbCr, in call order.
+    int nGains;
+    struct {
+        int channel;
+        int afterSubsampling;
+        float value;
+    } gains[4];
 };
 
 // Where a batch's files go: slot i starts at out + i * slotBytes and receives header i

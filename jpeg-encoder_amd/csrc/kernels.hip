@@ -195,13 +195,18 @@ __global__ __launch_bounds__(kGenThreads) void k_transform_generic(KGeom g, cons
                 const int sx = min(sx0 + dx, g.W - 1);
                 float r, gg, bb;
                 load_pixel(pix, g.strideBytes, g.sampleFormat, sx, sy, r, gg, bb);
-                const float v = channel_value(c, convert, r, gg, bb);
+                float v = channel_value(c, convert, r, gg, bb);
+                for (int o = 0; o < g.nGains; ++o)   // Encoder::multiplyColorChannelBy, Encoder.cpp:35-38
+                    if (g.gains[o].channel == c && !g.gains[o].afterSubsampling) v *= g.gains[o].value;
                 hsum = dx == 0 ? v : hsum + v;
             }
             hval = nw > 1 ? hsum / (float)wf : hsum;
             vsum = dy == 0 ? hval : vsum + hval;
         }
-        mine[i] = nh > 1 ? vsum / (float)hf : hval;
+        float reduced = nh > 1 ? vsum / (float)hf : hval;
+        for (int o = 0; o < g.nGains; ++o)
+            if (g.gains[o].channel == c && g.gains[o].afterSubsampling) reduced *= g.gains[o].value;
+        mine[i] = reduced;
     }
 
     float v[64];
@@ -619,7 +624,7 @@ static bool scheme_is(const KGeom& g, int wf, int hf, int method) {
 }
 
 hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef, hipStream_t s) {
-    const bool bytesAligned = g.sampleFormat == JPEG_HIP_RGB8 && g.stages == JPEG_HIP_STAGE_ALL &&
+    const bool bytesAligned = g.sampleFormat == JPEG_HIP_RGB8 && g.stages == JPEG_HIP_STAGE_ALL && g.nGains == 0 &&
                               (g.strideBytes & 3) == 0 && ((uintptr_t)d_rgb & 3) == 0 &&
                               (g.batch == 1 || (g.imageStrideBytes & 3) == 0);
     if (bytesAligned && scheme_is(g, 2, 2, JPEG_HIP_AVERAGE)) {

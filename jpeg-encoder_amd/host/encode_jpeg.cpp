@@ -1,7 +1,9 @@
 // Command line driver that replays the reference's EncodeJPEG call sequence
 // (JPEG-Encoder-SIMD.cpp:397-441) on the GPU-backed classes:
 //   encode_jpeg <source .ppm/.png> <destination .jpg> [444|422|411|420] [quality 1..100 | 0 = Annex K tables]
-//               [options: sepia, gain=<channel 0..2>:<factor>, standard-huffman, restart=<MCUs>]
+//               [options: sepia, gain=<channel 0..2>:<factor> (on R, G, B),
+//                ycbcr-gain=<channel>:<factor> (after convertToYCbCr), reduced-gain=<channel>:<factor>
+//                (after reduceResolutionBySchema), standard-huffman, restart=<MCUs>]
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -12,8 +14,8 @@
 
 struct Options {
     bool sepia = false, standardHuffman = false;
-    int gainChannel = -1, restart = 0;
-    float gain = 1.0f;
+    int gainChannel = -1, ycbcrGainChannel = -1, reducedGainChannel = -1, restart = 0;
+    float gain = 1.0f, ycbcrGain = 1.0f, reducedGain = 1.0f;
 };
 
 static void EncodeJPEG(const std::string& srcFile, const std::string& dstFile, const SamplingDefinition& scheme,
@@ -29,7 +31,10 @@ static void EncodeJPEG(const std::string& srcFile, const std::string& dstFile, c
     encoder->setStandardHuffmanTables(opt.standardHuffman);
     encoder->setRestartInterval(opt.restart);
     encoder->convertToYCbCr();
+    if (opt.ycbcrGainChannel >= 0) encoder->multiplyColorChannelBy((ColorChannelName)opt.ycbcrGainChannel, opt.ycbcrGain);
     encoder->reduceResolutionBySchema();
+    if (opt.reducedGainChannel >= 0)
+        encoder->multiplyColorChannelBy((ColorChannelName)opt.reducedGainChannel, opt.reducedGain);
     encoder->applyDCT(YCbCrColorName::Y);
     encoder->applyDCT(YCbCrColorName::Cb);
     encoder->applyDCT(YCbCrColorName::Cr);
@@ -55,6 +60,12 @@ int main(int argc, char* argv[]) {
         else if (a.rfind("gain=", 0) == 0 && a.size() > 7 && a[6] == ':') {
             opt.gainChannel = a[5] - '0';
             opt.gain = (float)atof(a.c_str() + 7);
+        } else if (a.rfind("ycbcr-gain=", 0) == 0 && a.size() > 13 && a[12] == ':') {
+            opt.ycbcrGainChannel = a[11] - '0';
+            opt.ycbcrGain = (float)atof(a.c_str() + 13);
+        } else if (a.rfind("reduced-gain=", 0) == 0 && a.size() > 15 && a[14] == ':') {
+            opt.reducedGainChannel = a[13] - '0';
+            opt.reducedGain = (float)atof(a.c_str() + 15);
         } else {
             std::cerr << "unknown option " << a << std::endl;
             return 1;

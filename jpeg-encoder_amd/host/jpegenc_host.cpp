@@ -330,9 +330,15 @@ void Encoder::convertToYCbCr() { stages |= JPEG_HIP_STAGE_YCBCR; }
 void Encoder::reduceResolutionBySchema() { stages |= JPEG_HIP_STAGE_SUBSAMPLE; }
 
 void Encoder::multiplyColorChannelBy(ColorChannelName channel, float val) {
-    if (stages != 0 || transformed)
-        throw std::runtime_error("multiplyColorChannelBy is supported on the R, G, B channels only (before convertToYCbCr)");
-    pixelOps.push_back({JPEG_HIP_FILTER_MULTIPLY, (int)channel, val});
+    if (transformed) throw std::runtime_error("multiplyColorChannelBy is not supported after applyDCT");
+    if (stages == 0) {   // the channels still are R, G, B
+        pixelOps.push_back({JPEG_HIP_FILTER_MULTIPLY, (int)channel, val});
+        return;
+    }
+    if (!(stages & JPEG_HIP_STAGE_YCBCR))
+        throw std::runtime_error("multiplyColorChannelBy after reduceResolutionBySchema needs convertToYCbCr first");
+    if (gainOps.size() >= JPEG_HIP_MAX_GAINS) throw std::runtime_error("too many multiplyColorChannelBy calls");
+    gainOps.push_back({(int)channel, (stages & JPEG_HIP_STAGE_SUBSAMPLE) != 0, val});
 }
 
 void Encoder::applySepia() {
@@ -352,6 +358,8 @@ void Encoder::ensureTransformed() {
               "jpeg_hip_upload_pixels");
     for (const PixelOp& op : pixelOps)
         check(jpeg_hip_filter_pixels(ctx, op.filter, op.channel, op.value), "jpeg_hip_filter_pixels");
+    for (const GainOp& op : gainOps)
+        check(jpeg_hip_channel_gain(ctx, op.channel, op.value, op.afterSubsampling ? 1 : 0), "jpeg_hip_channel_gain");
     check(jpeg_hip_transform(ctx, stages), "jpeg_hip_transform");
     transformed = true;
 }

@@ -263,6 +263,12 @@ private:
         float value;
     };
     std::vector<PixelOp> pixelOps;   // applied on the device, in order, after the upload
+    struct GainOp {
+        int channel;
+        bool afterSubsampling;
+        float value;
+    };
+    std::vector<GainOp> gainOps;     // multiplyColorChannelBy calls after convertToYCbCr, for the fused transform
     void open(const QTableSet& qtables);
     void ensureTransformed();
     void ensureTables();

@@ -27,7 +27,7 @@ EXPORTS = [
     "jpeg_hip_get_coefficients",
     "jpeg_hip_coefficients_device", "jpeg_hip_analyze_band", "jpeg_hip_finish_band", "jpeg_hip_set_profiling",
     "jpeg_hip_get_timings", "jpeg_hip_decode_info", "jpeg_hip_decode", "jpeg_hip_decode_host",
-    "jpeg_hip_decoded_coefficients", "jpeg_hip_psnr", "jpeg_hip_filter_pixels", "jpeg_hip_get_pixels",
+    "jpeg_hip_decoded_coefficients", "jpeg_hip_psnr", "jpeg_hip_filter_pixels", "jpeg_hip_get_pixels", "jpeg_hip_channel_gain",
 ]
 
 
@@ -98,6 +98,7 @@ def lib():
         L.jpeg_hip_bind_pixels.argtypes = [vp, vp, i32, i64]
         L.jpeg_hip_transform.argtypes = [vp, i32]
         L.jpeg_hip_filter_pixels.argtypes = [vp, i32, i32, C.c_float]
+        L.jpeg_hip_channel_gain.argtypes = [vp, i32, C.c_float, i32]
         L.jpeg_hip_get_pixels.argtypes = [vp, vp, i64]
         L.jpeg_hip_histograms.argtypes = [vp, vp]
         L.jpeg_hip_histograms_host.argtypes = [vp, vp]
@@ -349,6 +350,10 @@ class Context:
     # ---- pixel filters ----
     def filter_pixels(self, which, channel=0, value=1.0):
         self._check(lib().jpeg_hip_filter_pixels(self._h, which, channel, value))
+
+    def channel_gain(self, channel, value, after_subsampling=False):
+        """Encoder::multiplyColorChannelBy after convertToYCbCr: component 0 Y, 1 Cb, 2 Cr."""
+        self._check(lib().jpeg_hip_channel_gain(self._h, channel, value, 1 if after_subsampling else 0))
 
     def get_pixels(self, width, rows):
         out = np.zeros((rows, width, 3), np.float32)

@@ -371,6 +371,11 @@ struct BlockSymbols {
 
 // Fixed Huffman tables for the next encodes (extension; see encodeImage).
 bool g_fixedTables = false;
+// Encoder::multiplyColorChannelBy calls made after convertToYCbCr (Encoder.cpp:35-38): the
+// plane of `channel` is multiplied by `value`, before (stage 0) or after (stage 1)
+// reduceResolutionBySchema.
+struct GainOp { int channel; int stage; float value; };
+std::vector<GainOp> g_gains;
 u8 g_fixedLen[4][256];
 uint16_t g_fixedCode[4][256];
 
@@ -427,6 +432,10 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
         ch[0][i] = y; ch[1][i] = cb; ch[2][i] = cr;
     }
 
+    for (const GainOp& op : g_gains)        // multiplyAVX over the whole plane, SIMD256.h:246-258
+        if (op.stage == 0)
+            for (size_t i = 0; i < plane; ++i) ch[op.channel][i] *= op.value;
+
     // Encoder::reduceResolutionBySchema, Encoder.cpp:157-166: all width passes, then all
     // height passes, in place and compacting.
     int cw[3] = {simW, simW, simW}, chh[3] = {simH, simH, simH};
@@ -472,6 +481,9 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
         }
     }
     for (int c = 0; c < 3; ++c) { res.chW[c] = cw[c]; res.chH[c] = chh[c]; }
+    for (const GainOp& op : g_gains)
+        if (op.stage == 1)
+            for (int64_t i = 0; i < (int64_t)cw[op.channel] * chh[op.channel]; ++i) ch[op.channel][i] *= op.value;
 
     // Encoder::applyDCT per channel, Encoder.cpp:229-258.
     std::vector<BlockSymbols> sym[3];
@@ -729,6 +741,12 @@ void orc_set_fixed_tables(const uint8_t* lengths, const uint16_t* codes) {
         memcpy(g_fixedLen, lengths, sizeof g_fixedLen);
         memcpy(g_fixedCode, codes, sizeof g_fixedCode);
     }
+}
+
+// Channel gains applied by the following encodes (n = 0 switches them off).
+void orc_set_channel_gains(int n, const int32_t* channels, const int32_t* stages, const float* values) {
+    g_gains.clear();
+    for (int i = 0; i < n; ++i) g_gains.push_back({channels[i], stages[i], values[i]});
 }
 
 void orc_free(void* h) { delete (OrcResult*)h; }

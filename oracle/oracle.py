@@ -34,6 +34,8 @@ def lib():
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_set_fixed_tables.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_set_fixed_tables.restype = None
+        L.orc_set_channel_gains.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_set_channel_gains.restype = None
         for name in ("orc_jpeg_size", "orc_scan_offset", "orc_scan_len"):
             getattr(L, name).restype = C.c_int64
             getattr(L, name).argtypes = [C.c_void_p]
@@ -146,6 +148,16 @@ def set_fixed_tables(lengths=None, codes=None):
     ln = np.ascontiguousarray(lengths, np.uint8).reshape(4, 256)
     cd = np.ascontiguousarray(codes, np.uint16).reshape(4, 256)
     L.orc_set_fixed_tables(_p(ln), _p(cd))
+
+
+def set_channel_gains(ops=()):
+    """Encoder::multiplyColorChannelBy calls after convertToYCbCr, for the following encodes:
+    (channel, value, after_subsampling) triples in call order; empty switches them off."""
+    ops = list(ops)
+    ch = np.array([o[0] for o in ops], np.int32)
+    st = np.array([1 if o[2] else 0 for o in ops], np.int32)
+    va = np.array([o[1] for o in ops], np.float32)
+    lib().orc_set_channel_gains(len(ops), _p(ch), _p(st), _p(va))
 
 
 def encode(rgb, scheme, qtables, restart_interval=0, pad_ones=False, stride=None, hist_override=None, rst_base=0,

@@ -69,3 +69,47 @@ def test_filters_need_pixels_and_valid_arguments(ctx):
     with pytest.raises(B.JpegHipError) as e:
         ctx.filter_pixels(B.FILTER_MULTIPLY, 3, 2.0)
     assert e.value.status == B.ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("scheme", ["444", "420", "422", "411"])
+def test_channel_gain_after_colour_conversion(ctx, scheme):
+    # Encoder::multiplyColorChannelBy between convertToYCbCr and reduceResolutionBySchema
+    # (stage 0) and between reduceResolutionBySchema and applyDCT (stage 1), Encoder.cpp:35-38.
+    w, h = 123, 77
+    img = synth.generate("natural", w, h, seed=9)
+    qt = T.quality_tables(90)
+    ops = [(1, 0.5, False), (0, 1.25, False), (2, 0.8, True), (1, 1.5, True)]
+    prm = B.make_params(w, h, T.SCHEMES[scheme], qt)
+    lay = B.compute_layout(prm)
+    ctx.begin(prm)
+    ctx.upload_pixels(img)
+    for ch, val, after in ops:
+        ctx.channel_gain(ch, val, after)
+    ctx.transform()
+    O.set_channel_gains(ops)
+    try:
+        enc = O.encode(img, T.SCHEMES[scheme], qt)
+    finally:
+        O.set_channel_gains(())
+    for c in range(3):
+        assert np.array_equal(ctx.coefficients(c, lay), enc.coef[c]), (scheme, c)
+    ctx.build_huffman(ctx.histograms())
+    assert ctx.emit_scan_host() == enc.scan
+    # begin() forgets the gains: the same pixels now give the plain coefficients
+    ctx.begin(prm)
+    ctx.upload_pixels(img)
+    ctx.transform()
+    plain = O.encode(img, T.SCHEMES[scheme], qt)
+    for c in range(3):
+        assert np.array_equal(ctx.coefficients(c, lay), plain.coef[c]), (scheme, c)
+
+
+def test_channel_gain_argument_checks(ctx):
+    prm = B.make_params(16, 16, T.SCHEME_444, T.STANDARD_TABLES)
+    ctx.begin(prm)
+    with pytest.raises(B.JpegHipError):
+        ctx.channel_gain(3, 1.0)
+    for _ in range(4):
+        ctx.channel_gain(0, 1.0)
+    with pytest.raises(B.JpegHipError):
+        ctx.channel_gain(0, 1.0)

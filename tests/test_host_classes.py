@@ -113,6 +113,13 @@ def test_driver_options_filters_tables_restarts(tmp_path):
     sep[..., 0] = sep[..., 0] * F32(0.5)
     subprocess.check_call([exe, str(src), str(dst), "420", "90", "sepia", "gain=0:0.5"])
     assert dst.read_bytes() == O.encode(sep, T.SCHEME_420, T.quality_tables(90)).jpeg
+    # gains on the Cb plane after convertToYCbCr and on Y after reduceResolutionBySchema
+    subprocess.check_call([exe, str(src), str(dst), "420", "90", "ycbcr-gain=1:0.5", "reduced-gain=0:1.25"])
+    O.set_channel_gains([(1, 0.5, False), (0, 1.25, True)])
+    try:
+        assert dst.read_bytes() == O.encode(img, T.SCHEME_420, T.quality_tables(90)).jpeg
+    finally:
+        O.set_channel_gains(())
     # restart intervals through the class surface
     subprocess.check_call([exe, str(src), str(dst), "444", "0", "restart=6"])
     assert dst.read_bytes() == O.encode(img, T.SCHEME_444, T.STANDARD_TABLES, restart_interval=6).jpeg
