@@ -497,7 +497,9 @@ int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capac
 }
 
 // staged: the call comes from jpeg_hip_transform, which honours jpeg_hip_channel_gain.
-int do_transform(jpeg_hip_ctx* ctx, int stages, bool staged = false) {
+// clearHist: histograms the caller will count into right afterwards (do_histograms with
+// cleared = true).
+int do_transform(jpeg_hip_ctx* ctx, int stages, bool staged = false, uint64_t* clearHist = nullptr) {
     if (!ctx->begun || !ctx->hasPixels) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "transform needs begin() and pixels");
     const Geometry& g = ctx->geo;
     const bool subsampled = g.blocksPerMcu != 3;
@@ -514,16 +516,17 @@ int do_transform(jpeg_hip_ctx* ctx, int stages, bool staged = false) {
         }
     }
     mark(ctx, 0);
-    HIP_TRY(ctx, launch_transform(ctx->kg, ctx->rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, ctx->stream));
+    HIP_TRY(ctx, launch_transform(ctx->kg, ctx->rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, ctx->stream,
+                                  (unsigned long long*)clearHist));
     mark(ctx, 1);
     ctx->transformed = true;
     ctx->stagedScanLen = -1;
     return JPEG_HIP_OK;
 }
 
-int do_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist) {
+int do_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist, bool cleared = false) {
     if (!ctx->transformed) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "histograms need the transform");
-    HIP_TRY(ctx, launch_histogram(ctx->kg, (const int16_t*)ctx->coef.p, (unsigned long long*)d_hist, ctx->stream));
+    HIP_TRY(ctx, launch_histogram(ctx->kg, (const int16_t*)ctx->coef.p, (unsigned long long*)d_hist, ctx->stream, !cleared));
     mark(ctx, 2);
     return JPEG_HIP_OK;
 }
@@ -887,14 +890,16 @@ int jpeg_hip_analyze_band(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_forma
     if (st != JPEG_HIP_OK) return st;
     st = jpeg_hip_bind_pixels(ctx, d_rgb, sample_format, stride_bytes);
     if (st != JPEG_HIP_OK) return st;
-    st = do_transform(ctx, JPEG_HIP_STAGE_ALL);
+    // A null d_hist keeps the histograms in the context's own buffer.
+    uint64_t* hist = d_hist ? d_hist : (uint64_t*)ctx->hist.p;
+    const bool count = !ctx->prm.standard_huffman;   // fixed tables: nothing to count
+    st = do_transform(ctx, JPEG_HIP_STAGE_ALL, false, count ? hist : nullptr);
     if (st != JPEG_HIP_OK) return st;
-    if (ctx->prm.standard_huffman) {   // fixed tables: nothing to count
+    if (!count) {
         mark(ctx, 2);
         return JPEG_HIP_OK;
     }
-    // A null d_hist keeps the histograms in the context's own buffer.
-    return do_histograms(ctx, d_hist ? d_hist : (uint64_t*)ctx->hist.p);
+    return do_histograms(ctx, hist, true);
 }
 
 int jpeg_hip_finish_band(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t* d_out, int64_t out_capacity,
@@ -924,10 +929,10 @@ int jpeg_hip_encode_host(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format
     if (st != JPEG_HIP_OK) return st;
     st = jpeg_hip_upload_pixels(ctx, h_rgb, sample_format, stride_bytes);
     if (st != JPEG_HIP_OK) return st;
-    st = do_transform(ctx, JPEG_HIP_STAGE_ALL);
+    st = do_transform(ctx, JPEG_HIP_STAGE_ALL, false, params->standard_huffman ? nullptr : (uint64_t*)ctx->hist.p);
     if (st != JPEG_HIP_OK) return st;
     if (!params->standard_huffman) {
-        st = do_histograms(ctx, (uint64_t*)ctx->hist.p);
+        st = do_histograms(ctx, (uint64_t*)ctx->hist.p, true);
         if (st != JPEG_HIP_OK) return st;
     } else {
         mark(ctx, 2);

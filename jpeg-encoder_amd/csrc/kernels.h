@@ -75,8 +75,11 @@ struct EntropyWorkspace {
 
 constexpr int kStuffChunk = 4096;   // unstuffed bytes handled by one workgroup pass
 
-// Fused colour conversion + subsampling + DCT + quantization + zig-zag.
-hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef, hipStream_t s);
+// Fused colour conversion + subsampling + DCT + quantization + zig-zag.  d_clearHist, when
+// given, is one histogram set (uint64[4][256]) the kernel clears on the side for a following
+// launch_histogram(..., clear = false).
+hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef, hipStream_t s,
+                            unsigned long long* d_clearHist = nullptr);
 
 // Pixel filter (JPEG_HIP_FILTER_*) over `rows` rows of `width` pixels: src in sampleFormat
 // with srcStride bytes per row, dst float RGB with 3 * width floats per row (may be src).

@@ -162,9 +162,17 @@ __device__ __forceinline__ void block_in_mcu(const KGeom& g, int k, int& c, int&
 // ----------------------------------------------------------------------------------------
 constexpr int kGenThreads = 64;
 
+// Workgroup 0 of a transform kernel clears the histograms the following pass will count
+// into (one set of uint64[4][256]), which saves that pass a launch of its own.
+__device__ __forceinline__ void clear_histograms(u64* __restrict__ hist) {
+    if (hist != nullptr && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 1024; i += blockDim.x) hist[i] = 0;
+}
+
 __global__ __launch_bounds__(kGenThreads) void k_transform_generic(KGeom g, const void* __restrict__ rgb,
                                                                    const float* __restrict__ qtab,
-                                                                   int16_t* __restrict__ coef) {
+                                                                   int16_t* __restrict__ coef, u64* __restrict__ clearHist) {
+    clear_histograms(clearHist);
     __shared__ float samples[kGenThreads * 65];
     __shared__ float q[3 * 64];
     for (int i = threadIdx.x; i < 192; i += kGenThreads) q[i] = qtab[i];
@@ -440,7 +448,9 @@ constexpr int k420Mcus = 64;
 constexpr int kChromaPitch = 68;   // floats per block in LDS: keeps 16-byte rows, spreads banks
 
 __global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned char* __restrict__ rgb,
-                                                       const float* __restrict__ qtab, int16_t* __restrict__ coef) {
+                                                       const float* __restrict__ qtab, int16_t* __restrict__ coef,
+                                                       u64* __restrict__ clearHist) {
+    clear_histograms(clearHist);
     __shared__ __attribute__((aligned(16))) float chroma[2 * k420Mcus * kChromaPitch];
     __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 32 * kStagePitch];
     const float* rhi = qtab + 192;
@@ -532,7 +542,8 @@ constexpr int k444Positions = 64;
 
 __global__ __launch_bounds__(3 * k444Positions) void k_transform_444(KGeom g, const unsigned char* __restrict__ rgb,
                                                                      const float* __restrict__ qtab,
-                                                                     int16_t* __restrict__ coef) {
+                                                                     int16_t* __restrict__ coef, u64* __restrict__ clearHist) {
+    clear_histograms(clearHist);
     const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* rhi = qtab + 192 + 64 * c;
     const float* rlo = qtab + 384 + 64 * c;
@@ -623,21 +634,23 @@ static bool scheme_is(const KGeom& g, int wf, int hf, int method) {
     return true;
 }
 
-hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef, hipStream_t s) {
+hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef, hipStream_t s,
+                            unsigned long long* d_clearHist) {
     const bool bytesAligned = g.sampleFormat == JPEG_HIP_RGB8 && g.stages == JPEG_HIP_STAGE_ALL && g.nGains == 0 &&
                               (g.strideBytes & 3) == 0 && ((uintptr_t)d_rgb & 3) == 0 &&
                               (g.batch == 1 || (g.imageStrideBytes & 3) == 0);
     if (bytesAligned && scheme_is(g, 2, 2, JPEG_HIP_AVERAGE)) {
         const long long grid = (g.nMcu + k420Mcus - 1) / k420Mcus;
         hipLaunchKernelGGL(k_transform_420, dim3((unsigned)grid), dim3(256), 0, s, g, (const unsigned char*)d_rgb, d_qtab,
-                           d_coef);
+                           d_coef, d_clearHist);
     } else if (bytesAligned && scheme_is(g, 1, 1, JPEG_HIP_SUBSAMPLING)) {
         const long long grid = (g.nMcu + k444Positions - 1) / k444Positions;
         hipLaunchKernelGGL(k_transform_444, dim3((unsigned)grid), dim3(3 * k444Positions), 0, s, g,
-                           (const unsigned char*)d_rgb, d_qtab, d_coef);
+                           (const unsigned char*)d_rgb, d_qtab, d_coef, d_clearHist);
     } else {
         const long long grid = (g.totalBlocks + kGenThreads - 1) / kGenThreads;
-        hipLaunchKernelGGL(k_transform_generic, dim3((unsigned)grid), dim3(kGenThreads), 0, s, g, d_rgb, d_qtab, d_coef);
+        hipLaunchKernelGGL(k_transform_generic, dim3((unsigned)grid), dim3(kGenThreads), 0, s, g, d_rgb, d_qtab, d_coef,
+                           d_clearHist);
     }
     return hipGetLastError();
 }
