@@ -244,6 +244,8 @@ struct jpeg_hip_ctx {
         staging, batchHdr, batchHdrLen, batchFfStart, tileState, decCoef, decPlanes, decTables, decRgb, decSum, pixelsF, pipeIn[2], pipeOut;
     jpeghip::DecodedStream* decoded = nullptr;   // last file given to the verification decoder
     WorkerPool* workers = nullptr;               // created by the first batch pass
+    bool tablesPending = false;                  // pin->tables (+ pendingHeaderLen header bytes) are not on the device yet
+    int pendingHeaderLen = 0;
     int nGains = 0;                              // jpeg_hip_channel_gain calls since begin()
     struct {
         int channel, afterSubsampling;
@@ -412,14 +414,16 @@ hipError_t wait_event(hipEvent_t ev) {
     }
 }
 
-// Packs the tables for the kernels and sends them, together with headerLen bytes of file
-// header already placed in the pinned block, to the device in one copy.
+// Packs the tables for the kernels next to the headerLen bytes of file header already placed
+// in the pinned block.
 int install_tables(jpeg_hip_ctx* ctx, int headerLen = 0) {
     for (int t = 0; t < 4; ++t)
         for (int s = 0; s < 256; ++s)
             ctx->pin->tables[t * 256 + s] = ((uint32_t)ctx->lengths[t][s] << 16) | ctx->codes[t][s];
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->pin->tables, sizeof ctx->pin->tables + (size_t)headerLen,
-                                hipMemcpyHostToDevice, ctx->stream));
+    // They stay in the pinned block until the entropy stage runs: its first kernel fetches
+    // them from there (run_entropy).
+    ctx->tablesPending = true;
+    ctx->pendingHeaderLen = headerLen;
     ctx->hasTables = true;
     ctx->stagedScanLen = -1;
     ctx->streamBits = -1;
@@ -475,6 +479,15 @@ int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capac
     ctx->ws.avgBlockBits = ctx->streamBits < 0 ? -1 : ctx->streamBits / ((int64_t)ctx->geo.mcuRows * ctx->geo.mcusPerRow * ctx->geo.blocksPerMcu);
     ctx->ws.header = (const uint8_t*)ctx->tables.p + sizeof ctx->pin->tables;
     ctx->ws.headerLen = (int)prefix;
+    // A header staged with the tables is fetched with them; a launch without header (a
+    // repeated emit, a band inside the image) still has to bring the tables over.
+    ctx->ws.pendingTables = ctx->tablesPending ? ctx->pin->tables : nullptr;
+    if (ctx->tablesPending && (int64_t)ctx->pendingHeaderLen != prefix) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->pin->tables, sizeof ctx->pin->tables + (size_t)ctx->pendingHeaderLen,
+                                    hipMemcpyHostToDevice, ctx->stream));
+        ctx->ws.pendingTables = nullptr;
+    }
+    ctx->tablesPending = false;
     // Padding (< 1 byte) and a marker per interval on top of the coded bits, EOI, slack.
     // Without histograms the output capacity bounds the stream: a longer one fails anyway.
     ctx->ws.streamBound = ctx->streamBits < 0 ? capacity - prefix : ctx->streamBits / 8 + 3 * ctx->geo.intervals + 2 + 64;

@@ -71,6 +71,10 @@ struct EntropyWorkspace {
     long long avgBlockBits;          // mean entropy-coded bits per block according to the histograms, or < 0 when unknown
     const uint8_t* header;           // file header staged in device memory, copied to the front of the output
     int headerLen;                   // (0: none); prefixLen of launch_entropy covers it
+    // Tables (uint32[4][256]) and, right behind them, headerLen header bytes in pinned host
+    // memory that have not been sent to the device yet, or null: the first kernel of the
+    // stage fetches them into d_tables / header itself, which is cheaper than a copy call.
+    const uint32_t* pendingTables;
 };
 
 constexpr int kStuffChunk = 4096;   // unstuffed bytes handled by one workgroup pass

@@ -1620,8 +1620,16 @@ __global__ __launch_bounds__(256) void k_copy_headers(BatchOutput bo) {
 __global__ __launch_bounds__(256) void k_prepare_entropy(uint4* __restrict__ stream, long long stream16,
                                                          u64* __restrict__ tileState, long long tileWords,
                                                          u64* __restrict__ result, const uint8_t* __restrict__ hdr,
-                                                         int hdrLen, uint8_t* __restrict__ out) {
+                                                         int hdrLen, uint8_t* __restrict__ out,
+                                                         const u32* __restrict__ pending, u32* __restrict__ tables) {
     const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, step = (long long)gridDim.x * 256;
+    if (pending != nullptr) {
+        // Tables and header still sit in pinned host memory: bring them over (the device
+        // copy serves later launches) and take the header for the output from there.
+        const int words = 1024 + (hdrLen + 3) / 4;
+        for (long long i = tid; i < words; i += step) tables[i] = pending[i];
+        hdr = (const uint8_t*)(pending + 1024);
+    }
     for (long long i = tid; i < stream16; i += step) stream[i] = make_uint4(0, 0, 0, 0);
     for (long long i = tid; i < tileWords; i += step) tileState[i] = 0;
     if (tid < 4) result[tid] = 0;
@@ -1640,7 +1648,8 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     long long prepGrid = zero / 16 / (256 * 4);
     prepGrid = prepGrid < 1 ? 1 : (prepGrid > 2048 ? 2048 : prepGrid);
     hipLaunchKernelGGL(k_prepare_entropy, dim3((unsigned)prepGrid), dim3(256), 0, s, (uint4*)ws.unstuffed, zero / 16,
-                       ws.tileState, tileCount + 1, ws.result, ws.header, bo ? 0 : ws.headerLen, d_out);
+                       ws.tileState, tileCount + 1, ws.result, ws.header, bo ? 0 : ws.headerLen, d_out,
+                       bo ? nullptr : ws.pendingTables, const_cast<u32*>(d_tables));
     // Long blocks (noise, q=100) do not fit the private words; unknown lengths count as short.
     const bool shortBlocks = ws.avgBlockBits <= 128;
     if (shortBlocks)
