@@ -491,11 +491,12 @@ int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capac
     // Padding (< 1 byte) and a marker per interval on top of the coded bits, EOI, slack.
     // Without histograms the output capacity bounds the stream: a longer one fails anyway.
     ctx->ws.streamBound = ctx->streamBits < 0 ? capacity - prefix : ctx->streamBits / 8 + 3 * ctx->geo.intervals + 2 + 64;
+    // The kernels write length and error flags into the pinned record themselves.
+    ctx->pin->result[0] = ctx->pin->result[1] = ctx->pin->result[2] = 0;
+    ctx->ws.hostResult = (unsigned long long*)ctx->pin->result;
     HIP_TRY(ctx, launch_entropy(ctx->kg, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, d_out,
                                 prefix, capacity, writeEoi, ctx->stream));
     mark(ctx, 4);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin->result, ctx->result.p, sizeof ctx->pin->result, hipMemcpyDeviceToHost,
-                                ctx->stream));
     HIP_TRY(ctx, wait_stream(ctx));
     if (ctx->profiling) {
         float ms = 0;
@@ -503,7 +504,7 @@ int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capac
         if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->times[1] = ms;
         if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->times[2] = ms;
     }
-    if (ctx->pin->result[1] & 2) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer's tiles lost their chain");
+    if (ctx->pin->result[2] != 0) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer's tiles lost their chain");
     if (ctx->pin->result[1] != 0) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "output buffer is too small for the scan");
     *outLen = (int64_t)ctx->pin->result[0];
     return JPEG_HIP_OK;

@@ -75,6 +75,10 @@ struct EntropyWorkspace {
     // memory that have not been sent to the device yet, or null: the first kernel of the
     // stage fetches them into d_tables / header itself, which is cheaper than a copy call.
     const uint32_t* pendingTables;
+    // Pinned host copy of the result record, or null: [0] stuffed length, [1] output too
+    // small, [2] tile chain broken, written by the kernels themselves so that the host needs
+    // no copy after the stage (cleared by the host before the launch).
+    unsigned long long* hostResult;
 };
 
 constexpr int kStuffChunk = 4096;   // unstuffed bytes handled by one workgroup pass

@@ -1218,7 +1218,7 @@ template <bool kPrivate>
 __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int16_t* __restrict__ coef,
                                                              const u32* __restrict__ tables, u64* __restrict__ state,
                                                              u64* __restrict__ ivOff, u64* __restrict__ result,
-                                                             u32* __restrict__ words) {
+                                                             u32* __restrict__ words, u64* __restrict__ hostResult) {
     __shared__ u32 tab[4 * 256];
     constexpr int kStageWords = kPrivate ? kEmitStageShort : kEmitStageLong;
     __shared__ u32 stage[kStageWords];
@@ -1318,6 +1318,7 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
             if (!ok) {
                 start = p0;
                 result[1] = 2;
+                if (hostResult) hostResult[2] = 2;
             }
             __hip_atomic_store(state + tile, kTilePosition | pos_apply(whole, start), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -1495,7 +1496,8 @@ template <bool kBatch>
 __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __restrict__ buf,
                                                      const u64* __restrict__ ivOff, const u64* __restrict__ ffOff,
                                                      u64* __restrict__ result, uint8_t* __restrict__ out,
-                                                     long long prefixLen, long long outCapacity, BatchOutput bo) {
+                                                     long long prefixLen, long long outCapacity, BatchOutput bo,
+                                                     u64* __restrict__ hostResult) {
     __shared__ u64 lds[4];
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStuffStageBytes];
     const u64 bytes = result[2];
@@ -1527,7 +1529,10 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
         }
         if (onePiece) {
             if (base + (long long)total > limit) {
-                if (threadIdx.x == 0) result[1] = 1;
+                if (threadIdx.x == 0) {
+                    result[1] = 1;
+                    if (hostResult) hostResult[1] = 1;
+                }
             } else {
                 const int phase = (int)((uintptr_t)(out + base) & 3);
                 if (valid > 0) {
@@ -1577,7 +1582,10 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
             }
             if (overflow) result[1] = 1;
         }
-        if (!kBatch && ch == chunks - 1 && threadIdx.x == 0) result[0] = (u64)(base + (long long)total);
+        if (!kBatch && ch == chunks - 1 && threadIdx.x == 0) {
+            result[0] = (u64)(base + (long long)total);
+            if (hostResult) hostResult[0] = (u64)(base + (long long)total);
+        }
         __syncthreads();
     }
 }
@@ -1654,10 +1662,10 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     const bool shortBlocks = ws.avgBlockBits <= 128;
     if (shortBlocks)
         hipLaunchKernelGGL(k_encode_bits<true>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
-                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed);
+                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult);
     else
         hipLaunchKernelGGL(k_encode_bits<false>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
-                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed);
+                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult);
     // Chunks the stream can have at most: from the bound that was cleared.
     long long chunkBound = zero / kStuffChunk + 1;
     if (chunkBound > ws.maxChunks) chunkBound = ws.maxChunks;
@@ -1674,11 +1682,11 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
                            ws.ffOff, ws.result, bo->ffStart);
         hipLaunchKernelGGL(k_copy_headers, dim3((unsigned)g.batch), dim3(256), 0, s, *bo);
         hipLaunchKernelGGL(k_stuff_bytes<true>, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
-                           ws.ffOff, ws.result, bo->out, 0, 0, *bo);
+                           ws.ffOff, ws.result, bo->out, 0, 0, *bo, nullptr);
     } else {
         BatchOutput none = {};
         hipLaunchKernelGGL(k_stuff_bytes<false>, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
-                           ws.ffOff, ws.result, d_out, prefixLen, outCapacity, none);
+                           ws.ffOff, ws.result, d_out, prefixLen, outCapacity, none, ws.hostResult);
     }
     return hipGetLastError();
 }
