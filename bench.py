@@ -167,7 +167,8 @@ def main():
             cur.wait_stream(ext)
             dist.all_reduce(hist)
             ext.wait_stream(cur)
-        return ctx.finish_band(hist.data_ptr(), out.data_ptr(), cap)
+        # One rank: the band's own histograms are the image's, no summed copy to hand back.
+        return ctx.finish_band(hist.data_ptr() if world > 1 else None, out.data_ptr(), cap)
 
     def sync():
         if world > 1:

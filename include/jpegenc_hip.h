@@ -253,7 +253,10 @@ int jpeg_hip_analyze_band(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_forma
                           const jpeg_hip_params* params, uint64_t* d_hist);
 /* Second half: tables from the summed histograms (host copy made internally), then this
  * band's piece of the file: headers if the band starts the image, the band's scan bytes,
- * EOI if the band ends the image.  Concatenating the pieces in band order gives the file. */
+ * EOI if the band ends the image.  Concatenating the pieces in band order gives the file.
+ * d_hist_sum may be null when the band is the whole image: the histograms are then taken
+ * as jpeg_hip_analyze_band counted them (the kernel leaves a copy with the host, so no
+ * transfer is needed). */
 int jpeg_hip_finish_band(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t* d_out, int64_t out_capacity,
                          int64_t* out_len);
 

@@ -244,6 +244,9 @@ struct jpeg_hip_ctx {
         staging, batchHdr, batchHdrLen, batchFfStart, tileState, decCoef, decPlanes, decTables, decRgb, decSum, pixelsF, pipeIn[2], pipeOut;
     jpeghip::DecodedStream* decoded = nullptr;   // last file given to the verification decoder
     WorkerPool* workers = nullptr;               // created by the first batch pass
+    DevBuf histDone;                             // counter of the histogram kernel's host export
+    unsigned long long histExpected = 0;         // value of that counter once every launch so far has finished
+    bool histOnHost = false;                     // pin->hist holds the current band's histograms as counted
     bool tablesPending = false;                  // pin->tables (+ pendingHeaderLen header bytes) are not on the device yet
     int pendingHeaderLen = 0;
     int nGains = 0;                              // jpeg_hip_channel_gain calls since begin()
@@ -538,9 +541,28 @@ int do_transform(jpeg_hip_ctx* ctx, int stages, bool staged = false, uint64_t* c
     return JPEG_HIP_OK;
 }
 
-int do_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist, bool cleared = false) {
+// toHost: the kernel also leaves the finished histograms in the pinned block (pin->hist), for
+// a finish step that is told to use them as they are.
+int do_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist, bool cleared = false, bool toHost = false) {
     if (!ctx->transformed) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "histograms need the transform");
-    HIP_TRY(ctx, launch_histogram(ctx->kg, (const int16_t*)ctx->coef.p, (unsigned long long*)d_hist, ctx->stream, !cleared));
+    ctx->histOnHost = false;
+    HistogramExport ex = {nullptr, 0, nullptr};
+    if (toHost) {
+        if (!ctx->histDone.p) {   // the workgroups' counter starts at zero and is never reset
+            HIP_TRY(ctx, ctx->histDone.ensure(8));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->histDone.p, 0, 8, ctx->stream));
+            ctx->histExpected = 0;
+        }
+        ex.counter = (unsigned long long*)ctx->histDone.p;
+        ex.expected = ctx->histExpected;
+        ex.host = (unsigned long long*)ctx->pin->hist;
+    }
+    HIP_TRY(ctx, launch_histogram(ctx->kg, (const int16_t*)ctx->coef.p, (unsigned long long*)d_hist, ctx->stream, !cleared,
+                                  toHost ? &ex : nullptr));
+    if (toHost) {
+        ctx->histExpected = ex.expected;
+        ctx->histOnHost = true;
+    }
     mark(ctx, 2);
     return JPEG_HIP_OK;
 }
@@ -548,6 +570,12 @@ int do_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist, bool cleared = false) {
 // Histograms to the host (not for the standard tables), tables and header to the device.
 int fetch_hist_and_build(jpeg_hip_ctx* ctx, const uint64_t* d_hist, int64_t capacity, int* headerLen) {
     if (ctx->prm.standard_huffman) return build_tables(ctx, nullptr, true, capacity, headerLen);
+    if (!d_hist) {   // the band's own histograms, which the kernel has put into the pinned block
+        if (!ctx->histOnHost) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "no histograms of this band: pass the summed ones");
+        HIP_TRY(ctx, wait_stream(ctx));
+        return build_tables(ctx, ctx->pin->hist, true, capacity, headerLen);
+    }
+    ctx->histOnHost = false;   // the pinned block is about to hold the caller's histograms
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pin->hist, d_hist, sizeof ctx->pin->hist, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, wait_stream(ctx));
     return build_tables(ctx, ctx->pin->hist, true, capacity, headerLen);
@@ -600,7 +628,7 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->ffOff, &ctx->scanTmp, &ctx->result,
                       &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart,
                       &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum, &ctx->pixelsF, &ctx->pipeIn[0], &ctx->pipeIn[1],
-                      &ctx->pipeOut};
+                      &ctx->pipeOut, &ctx->histDone};
     delete ctx->decoded;
     delete ctx->workers;
     for (DevBuf* b : bufs) b->release();
@@ -665,6 +693,7 @@ int jpeg_hip_begin(jpeg_hip_ctx* ctx, const jpeg_hip_params* params) {
     ctx->geo = g;
     ctx->begun = true;
     ctx->hasPixels = ctx->transformed = ctx->hasTables = false;
+    ctx->histOnHost = false;
     ctx->nGains = 0;
     const int ws = ensure_workspace(ctx);
     if (ws != JPEG_HIP_OK) return ws;
@@ -913,14 +942,13 @@ int jpeg_hip_analyze_band(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_forma
         mark(ctx, 2);
         return JPEG_HIP_OK;
     }
-    return do_histograms(ctx, hist, true);
+    return do_histograms(ctx, hist, true, true);
 }
 
 int jpeg_hip_finish_band(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t* d_out, int64_t out_capacity,
                          int64_t* out_len) {
     if (!ctx || !d_out || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (!ctx->transformed) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "finish needs analyze");
-    if (!ctx->prm.standard_huffman && !d_hist_sum) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int headerLen = 0;
     const int st = fetch_hist_and_build(ctx, d_hist_sum, out_capacity, &headerLen);
@@ -933,7 +961,7 @@ int jpeg_hip_encode(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int
     if (!ctx || !d_out || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     int st = jpeg_hip_analyze_band(ctx, d_rgb, sample_format, stride_bytes, params, nullptr);
     if (st != JPEG_HIP_OK) return st;
-    return jpeg_hip_finish_band(ctx, (const uint64_t*)ctx->hist.p, d_out, out_capacity, out_len);
+    return jpeg_hip_finish_band(ctx, nullptr, d_out, out_capacity, out_len);
 }
 
 int jpeg_hip_encode_host(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format, int64_t stride_bytes,
@@ -946,7 +974,7 @@ int jpeg_hip_encode_host(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format
     st = do_transform(ctx, JPEG_HIP_STAGE_ALL, false, params->standard_huffman ? nullptr : (uint64_t*)ctx->hist.p);
     if (st != JPEG_HIP_OK) return st;
     if (!params->standard_huffman) {
-        st = do_histograms(ctx, (uint64_t*)ctx->hist.p, true);
+        st = do_histograms(ctx, (uint64_t*)ctx->hist.p, true, true);
         if (st != JPEG_HIP_OK) return st;
     } else {
         mark(ctx, 2);
@@ -957,7 +985,7 @@ int jpeg_hip_encode_host(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format
     HIP_TRY(ctx, ctx->staging.ensure((size_t)lay.max_jpeg_bytes));
     ctx->stagedScanLen = -1;
     int64_t len = 0;
-    st = jpeg_hip_finish_band(ctx, (const uint64_t*)ctx->hist.p, (uint8_t*)ctx->staging.p, lay.max_jpeg_bytes, &len);
+    st = jpeg_hip_finish_band(ctx, nullptr, (uint8_t*)ctx->staging.p, lay.max_jpeg_bytes, &len);
     if (st != JPEG_HIP_OK) return st;
     if (len > out_capacity) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "host output buffer too small");
     HIP_TRY(ctx, hipMemcpyAsync(h_out, ctx->staging.p, (size_t)len, hipMemcpyDeviceToHost, ctx->stream));

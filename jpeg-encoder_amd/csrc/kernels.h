@@ -96,8 +96,16 @@ hipError_t launch_pixel_filter(const void* d_src, int sampleFormat, long long sr
 
 // Symbol histograms (uint64[4][256] per image of the batch); d_hist is cleared first unless
 // the caller has done that (launch_clear_histograms) for several launches at once.
+// ex (single images only): the kernel also writes the finished histograms to ex->host, pinned
+// host memory, so that the host needs no copy; ex->counter is a device word the workgroups
+// count themselves off with, never reset, and ex->expected follows it from launch to launch.
+struct HistogramExport {
+    unsigned long long* counter;
+    unsigned long long expected;
+    unsigned long long* host;
+};
 hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, unsigned long long* d_hist, hipStream_t s,
-                            bool clear = true);
+                            bool clear = true, HistogramExport* ex = nullptr);
 hipError_t launch_clear_histograms(unsigned long long* d_hist, int images, hipStream_t s);
 
 // Single-pass bit writer (lengths, positions, bits) and byte stuffing.  d_tables:

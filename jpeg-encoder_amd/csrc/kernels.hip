@@ -771,8 +771,9 @@ struct HistVisitor {
 // blockIdx.y is the image of the batch; a workgroup never mixes images, so its LDS counts
 // belong to one histogram set.
 __global__ __launch_bounds__(kEntThreads) void k_histogram(KGeom g, const int16_t* __restrict__ coef,
-                                                           u64* __restrict__ hist) {
+                                                           u64* __restrict__ hist, HistogramExport ex) {
     __shared__ u32 lh[4 * 256];   // DC-Y, DC-C, AC-Y, AC-C (Encoder.cpp:368-416)
+    __shared__ bool lastOne;
     for (int i = threadIdx.x; i < 1024; i += kEntThreads) lh[i] = 0;
     __syncthreads();
     const int16_t* image = coef + (long long)blockIdx.y * g.blocksPerImage * 64;
@@ -794,8 +795,34 @@ __global__ __launch_bounds__(kEntThreads) void k_histogram(KGeom g, const int16_
     }
     __syncthreads();
     u64* mine = hist + (long long)blockIdx.y * 1024;
+    if (ex.host == nullptr) {
+        for (int i = threadIdx.x; i < 1024; i += kEntThreads)
+            if (lh[i] != 0) atomicAdd(&mine[i], (u64)lh[i]);
+        return;
+    }
+    // The workgroup that finishes last hands the complete histograms to the host.  No
+    // fences (a release at device scope writes the whole L2 back, once per workgroup): the
+    // additions return their old values, so they have been performed when the workgroup
+    // counts itself off, and the last one reads the sums where the additions were made.
+    // The counter is never reset: the launcher tells which value the last one will see.
+    u64 old[1024 / kEntThreads];
+#pragma unroll
+    for (int k = 0; k < 1024 / kEntThreads; ++k) {   // all in flight before the first is waited for
+        const u32 v = lh[k * kEntThreads + threadIdx.x];
+        old[k] = v != 0 ? atomicAdd(&mine[k * kEntThreads + threadIdx.x], (u64)v) : 0;
+    }
+    u64 seen = 0;
+#pragma unroll
+    for (int k = 0; k < 1024 / kEntThreads; ++k) seen |= old[k];
+    // `seen` is there to be waited for, in front of the barrier: a store that depends on it
+    // (under a condition that never holds) cannot move behind.
+    if (seen == ~0ull) lh[0] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) lastOne = atomicAdd(ex.counter, 1ull) + 1 == ex.expected;
+    __syncthreads();
+    if (!lastOne) return;
     for (int i = threadIdx.x; i < 1024; i += kEntThreads)
-        if (lh[i] != 0) atomicAdd(&mine[i], (u64)lh[i]);
+        ex.host[i] = __hip_atomic_load(&hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Zeroes n 8-byte words.  A kernel rather than hipMemsetAsync: a launch costs the host a
@@ -811,7 +838,8 @@ hipError_t launch_clear_histograms(unsigned long long* d_hist, int images, hipSt
     return hipGetLastError();
 }
 
-hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, bool clear) {
+hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, bool clear,
+                            HistogramExport* ex) {
     if (clear) {
         const hipError_t e = launch_clear_histograms(d_hist, g.batch, s);
         if (e != hipSuccess) return e;
@@ -822,7 +850,10 @@ hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, 
     const long long rounds = (passes + cap - 1) / cap;
     long long grid = (passes + rounds - 1) / rounds;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_histogram, dim3((unsigned)grid, (unsigned)g.batch), dim3(kEntThreads), 0, s, g, d_coef, d_hist);
+    HistogramExport none = {nullptr, 0, nullptr};
+    if (ex != nullptr && g.batch == 1) ex->expected += (unsigned long long)grid;   // what the counter reads when all are done
+    hipLaunchKernelGGL(k_histogram, dim3((unsigned)grid, (unsigned)g.batch), dim3(kEntThreads), 0, s, g, d_coef, d_hist,
+                       ex != nullptr && g.batch == 1 ? *ex : none);
     return hipGetLastError();
 }
 

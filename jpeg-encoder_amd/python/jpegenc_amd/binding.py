@@ -340,7 +340,8 @@ class Context:
 
     def finish_band(self, d_hist_sum, d_out, capacity):
         n = C.c_int64(0)
-        self._check(lib().jpeg_hip_finish_band(self._h, C.c_void_p(d_hist_sum), C.c_void_p(d_out), capacity,
+        # d_hist_sum None: the band is the whole image, use the histograms as analyze_band counted them
+        self._check(lib().jpeg_hip_finish_band(self._h, C.c_void_p(d_hist_sum) if d_hist_sum else None, C.c_void_p(d_out), capacity,
                                                C.byref(n)))
         return n.value
 

@@ -148,3 +148,30 @@ def test_noise_q100_worst_case(ctx):
         got = ctx.encode_host(img, prm)
         assert hashlib.sha256(got).hexdigest() == hashlib.sha256(enc.jpeg).hexdigest()
         assert enc.lengths.max() == 16
+
+
+def test_whole_image_band_without_summed_histograms(ctx):
+    # finish_band(None): the band is the whole image and its histograms are used as
+    # analyze_band counted them (the kernel leaves a copy with the host).  Interleaved with
+    # the explicit form and with different sizes, so a stale host copy would show.
+    import torch
+    qt = T.quality_tables(90)
+    d_hist = torch.zeros((4, 256), dtype=torch.int64, device="cuda")
+    d_out = torch.zeros(4 << 20, dtype=torch.uint8, device="cuda")
+    for k, (w, h, scheme) in enumerate([(333, 270, "420"), (64, 48, "444"), (800, 601, "420"), (37, 29, "422")]):
+        img = synth.generate("natural" if k % 2 == 0 else "noise", w, h, seed=30 + k)
+        d_rgb = torch.from_numpy(img).cuda()
+        prm = B.make_params(w, h, T.SCHEMES[scheme], qt)
+        want = O.encode(img, T.SCHEMES[scheme], qt).jpeg
+        ctx.analyze_band(d_rgb.data_ptr(), B.RGB8, w * 3, prm, d_hist.data_ptr())
+        n = ctx.finish_band(None, d_out.data_ptr(), d_out.numel())
+        assert d_out[:n].cpu().numpy().tobytes() == want, (w, h, scheme, "own")
+        n = ctx.finish_band(d_hist.data_ptr(), d_out.data_ptr(), d_out.numel())
+        assert d_out[:n].cpu().numpy().tobytes() == want, (w, h, scheme, "explicit")
+    # after histograms counted through the staged call there is no host copy to fall back on
+    ctx.begin(prm)
+    ctx.upload_pixels(img)
+    ctx.transform()
+    ctx.histograms()
+    with pytest.raises(B.JpegHipError):
+        ctx.finish_band(None, d_out.data_ptr(), d_out.numel())
