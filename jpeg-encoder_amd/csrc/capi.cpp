@@ -261,8 +261,7 @@ struct jpeg_hip_ctx {
     hipStream_t tableStream = nullptr;           // ... and its tables and headers to the device
     hipEvent_t partCounted[kBatchParts] = {};    // a part of a batch pass has its histograms
     hipEvent_t partEvent[kBatchParts] = {};      // ... and they are on the host
-    hipEvent_t partTime[kBatchParts][4] = {};    // profiling: around the part's transform, around its histogram pass
-    bool partTimed[kBatchParts] = {};            // the part started a transform launch in the current pass
+    hipEvent_t groupTime[2][3] = {};             // profiling: before a group's transform, behind it, behind its histogram parts
     EntropyWorkspace ws;
     Pinned* pin = nullptr;
     uint8_t lengths[4][256];
@@ -640,8 +639,8 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
         if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->partCounted)
         if (e) (void)hipEventDestroy(e);
-    for (auto& part : ctx->partTime)
-        for (auto& e : part)
+    for (auto& grp : ctx->groupTime)
+        for (auto& e : grp)
             if (e) (void)hipEventDestroy(e);
     if (ctx->histStream) (void)hipStreamDestroy(ctx->histStream);
     if (ctx->tableStream) (void)hipStreamDestroy(ctx->tableStream);
@@ -1107,22 +1106,20 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     for (int grp = 0; grp < groups; ++grp) {
         const int p0 = parts * grp / groups, p1 = parts * (grp + 1) / groups;
         const int ga = partBegin[p0], gcnt = partBegin[p1] - ga;
+        // Timing events sit at the group's edges only: an event between two kernels costs
+        // the stream more than ten microseconds.
         if (ctx->profiling) {
-            for (int p = p0; p < p1; ++p)
-                for (auto& e : ctx->partTime[p])
-                    if (!e) HIP_TRY(ctx, hipEventCreate(&e));
-            HIP_TRY(ctx, hipEventRecord(ctx->partTime[p0][0], ctx->stream));
+            for (auto& e : ctx->groupTime[grp])
+                if (!e) HIP_TRY(ctx, hipEventCreate(&e));
+            HIP_TRY(ctx, hipEventRecord(ctx->groupTime[grp][0], ctx->stream));
         }
-        for (int p = p0; p < p1; ++p) ctx->partTimed[p] = p == p0;
         HIP_TRY(ctx, launch_transform(part_geometry(ga, gcnt), d_rgb + (int64_t)ga * imageStride, (const float*)ctx->qtab.p,
                                       (int16_t*)ctx->coef.p + (int64_t)ga * g.totalBlocks * 64, ctx->stream));
-        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->partTime[p0][1], ctx->stream));
+        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->groupTime[grp][1], ctx->stream));
         for (int p = p0; p < p1; ++p) {
             const int a = partBegin[p], cnt = partBegin[p + 1] - a;
-            if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->partTime[p][2], ctx->stream));
             HIP_TRY(ctx, launch_histogram(part_geometry(a, cnt), (const int16_t*)ctx->coef.p + (int64_t)a * g.totalBlocks * 64,
                                           (unsigned long long*)ctx->hist.p + (size_t)a * 1024, ctx->stream, false));
-            if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->partTime[p][3], ctx->stream));
             if (!ctx->partCounted[p]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->partCounted[p], hipEventDisableTiming));
             if (!ctx->partEvent[p]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->partEvent[p], hipEventDisableTiming));
             HIP_TRY(ctx, hipEventRecord(ctx->partCounted[p], ctx->stream));
@@ -1131,6 +1128,7 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
                                         (size_t)cnt * 1024 * 8, hipMemcpyDeviceToHost, ctx->histStream));
             HIP_TRY(ctx, hipEventRecord(ctx->partEvent[p], ctx->histStream));
         }
+        if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->groupTime[grp][2], ctx->stream));
     }
     if (!ctx->workers) {
         const unsigned hw = std::thread::hardware_concurrency();
@@ -1202,12 +1200,9 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
         if (standard) {
             if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->times[0] += ms;
         } else {
-            // A part that did not start a transform launch left its first two events
-            // unrecorded in this pass; those report an error or a stale pair, both skipped.
-            for (int p = 0; p < parts; ++p) {
-                if (ctx->partTimed[p] && hipEventElapsedTime(&ms, ctx->partTime[p][0], ctx->partTime[p][1]) == hipSuccess)
-                    ctx->times[0] += ms;
-                if (hipEventElapsedTime(&ms, ctx->partTime[p][2], ctx->partTime[p][3]) == hipSuccess) ctx->times[1] += ms;
+            for (int grp = 0; grp < (parts >= 4 ? 2 : 1); ++grp) {
+                if (hipEventElapsedTime(&ms, ctx->groupTime[grp][0], ctx->groupTime[grp][1]) == hipSuccess) ctx->times[0] += ms;
+                if (hipEventElapsedTime(&ms, ctx->groupTime[grp][1], ctx->groupTime[grp][2]) == hipSuccess) ctx->times[1] += ms;
             }
         }
         if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->times[2] += ms;
