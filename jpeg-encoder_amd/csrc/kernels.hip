@@ -846,7 +846,11 @@ hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, 
     }
     // Every workgroup takes the same number of 256-block passes.
     const long long passes = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
-    const long long cap = g.batch > 1 ? (4096 / g.batch > 8 ? 4096 / g.batch : 8) : 2048;
+    // A workgroup ends with a flush of up to 1024 counters: a mid-sized image is better off
+    // with two passes per workgroup than with twice the workgroups (4K 4:4:4: 40 -> 26 us),
+    // a small one needs every workgroup it can get.
+    long long cap = g.batch > 1 ? (4096 / g.batch > 8 ? 4096 / g.batch : 8) : 2048;
+    if (g.batch == 1 && passes / 2 < cap) cap = passes / 2 > 256 ? passes / 2 : 256;
     const long long rounds = (passes + cap - 1) / cap;
     long long grid = (passes + rounds - 1) / rounds;
     if (grid < 1) grid = 1;
