@@ -82,8 +82,8 @@ def cpu_baseline(width, height, scheme, qt, kind):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="16k_420_q90", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU and step (batch workload)")
     ap.add_argument("--standard-huffman", action="store_true",
