@@ -240,7 +240,7 @@ struct jpeg_hip_ctx {
     const void* rgb = nullptr;
     int fmt = JPEG_HIP_RGB8;
     int64_t stride = 0;
-    DevBuf pixels, coef, qtab, hist, tables, ivOff, ffCount, ffOff, scanTmp, result, unstuffed,
+    DevBuf pixels, coef, qtab, hist, tables, ivOff, ffCount, groupSum, result, unstuffed,
         staging, batchHdr, batchHdrLen, batchFfStart, tileState, decCoef, decPlanes, decTables, decRgb, decSum, pixelsF, pipeIn[2], pipeOut;
     jpeghip::DecodedStream* decoded = nullptr;   // last file given to the verification decoder
     WorkerPool* workers = nullptr;               // created by the first batch pass
@@ -349,15 +349,13 @@ int ensure_workspace(jpeg_hip_ctx* ctx, int images = 1) {
     // Entropy-coded bits plus the RSTn/EOI markers the bit writer places in the stream.
     const int64_t unstuffedCap = (worst_case_scan_bytes(nb) + 2 * intervals + 2 + kStuffChunk + 63) / 16 * 16;
     const int64_t maxChunks = (unstuffedCap + kStuffChunk - 1) / kStuffChunk;
-    const int64_t scanItems = maxChunks;
     HIP_TRY(ctx, ctx->coef.ensure((size_t)nb * 128));
     HIP_TRY(ctx, ctx->qtab.ensure(sizeof ctx->pin->qtab));
     HIP_TRY(ctx, ctx->hist.ensure(1024 * sizeof(uint64_t) * images));
     HIP_TRY(ctx, ctx->tables.ensure(1024 * sizeof(uint32_t) * images + kHeaderCapacity));
     HIP_TRY(ctx, ctx->ivOff.ensure((size_t)(intervals + 1) * 8));
     HIP_TRY(ctx, ctx->ffCount.ensure((size_t)maxChunks * 4));
-    HIP_TRY(ctx, ctx->ffOff.ensure((size_t)(maxChunks + 1) * 8));
-    HIP_TRY(ctx, ctx->scanTmp.ensure((size_t)(scanItems / 2048 + 2) * 8));
+    HIP_TRY(ctx, ctx->groupSum.ensure((size_t)(maxChunks / 64 + 2) * 8));
     HIP_TRY(ctx, ctx->result.ensure(4 * 8));
     HIP_TRY(ctx, ctx->unstuffed.ensure((size_t)unstuffedCap));
     const int64_t tiles = (g.totalBlocks + 255) / 256 * images;
@@ -365,8 +363,9 @@ int ensure_workspace(jpeg_hip_ctx* ctx, int images = 1) {
     EntropyWorkspace& ws = ctx->ws;
     ws.ivOff = (unsigned long long*)ctx->ivOff.p;
     ws.ffCount = (uint32_t*)ctx->ffCount.p;
-    ws.ffOff = (unsigned long long*)ctx->ffOff.p;
-    ws.scanTmp = (unsigned long long*)ctx->scanTmp.p;
+    ws.groupSum = (unsigned long long*)ctx->groupSum.p;
+    // Diagnostic switch: the chunk count from which the stuffing pass uses group sums.
+    ws.groupSumsFrom = getenv("JPEGENC_GROUP_SUMS_FROM") ? atoll(getenv("JPEGENC_GROUP_SUMS_FROM")) : 0;
     ws.result = (unsigned long long*)ctx->result.p;
     ws.unstuffed = (uint8_t*)ctx->unstuffed.p;
     ws.unstuffedCap = unstuffedCap;
@@ -624,7 +623,7 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->ffOff, &ctx->scanTmp, &ctx->result,
+    DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->groupSum, &ctx->result,
                       &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart,
                       &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum, &ctx->pixelsF, &ctx->pipeIn[0], &ctx->pipeIn[1],
                       &ctx->pipeOut, &ctx->histDone};

@@ -59,8 +59,8 @@ struct BatchOutput {
 struct EntropyWorkspace {
     unsigned long long* ivOff;   // [intervals + 1]: byte offset of every interval in the unstuffed stream
     uint32_t* ffCount;           // [maxChunks]
-    unsigned long long* ffOff;   // [maxChunks + 1]
-    unsigned long long* scanTmp; // scratch for the scans
+    unsigned long long* groupSum; // [maxChunks / 64 + 1]: the counts of 64 consecutive chunks added up
+    long long groupSumsFrom;      // streams of more chunks than this get the group sums (0: the built-in limit)
     unsigned long long* result;  // [4]: stuffed length, error flags (1: output too small, 2: tile chain broken),
                                  //      unstuffed bytes, number of 4 KiB chunks
     uint8_t* unstuffed;          // [unstuffedCap]

@@ -873,11 +873,8 @@ struct LengthVisitor {
     __device__ __forceinline__ void eob() { bits += acTab[0] >> 16; }
 };
 
-// ---- exclusive scans ---------------------------------------------------------------------
-// out[i] = sum of in[0..i), out[n] = total.  n is read from device memory when dN is set.
+// ---- workgroup scan ----------------------------------------------------------------------
 constexpr int kScanThreads = 256;
-constexpr int kScanItems = 8;
-constexpr int kScanTile = kScanThreads * kScanItems;
 
 __device__ __forceinline__ u64 wave_inclusive_scan(u64 v) {
     const int lane = threadIdx.x & 63;
@@ -906,131 +903,6 @@ __device__ __forceinline__ u64 block_exclusive_scan(u64 v, u64* lds, u64& total)
     }
     total = sum;
     return base + inc - v;
-}
-
-template <typename TIn>
-__global__ __launch_bounds__(kScanThreads) void k_scan_tile_sums(const TIn* __restrict__ in, long long nHost,
-                                                                 const u64* __restrict__ dN, u64* __restrict__ tileSums) {
-    __shared__ u64 lds[4];
-    const long long n = dN ? (long long)*dN : nHost;
-    const long long tiles = (n + kScanTile - 1) / kScanTile;
-    for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const long long base = t * kScanTile + (long long)threadIdx.x * kScanItems;
-        u64 s = 0;
-#pragma unroll
-        for (int i = 0; i < kScanItems; ++i)
-            if (base + i < n) s += (u64)in[base + i];
-        u64 total;
-        block_exclusive_scan(s, lds, total);
-        if (threadIdx.x == 0) tileSums[t] = total;
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(kScanThreads) void k_scan_tile_offsets(long long nHost, const u64* __restrict__ dN,
-                                                                    u64* __restrict__ tileSums) {
-    __shared__ u64 lds[4];
-    const long long n = dN ? (long long)*dN : nHost;
-    const long long tiles = (n + kScanTile - 1) / kScanTile;
-    u64 carry = 0;
-    for (long long t0 = 0; t0 < tiles; t0 += kScanThreads) {
-        const long long t = t0 + threadIdx.x;
-        const u64 v = t < tiles ? tileSums[t] : 0;
-        u64 total;
-        const u64 ex = block_exclusive_scan(v, lds, total);
-        if (t < tiles) tileSums[t] = carry + ex;
-        carry += total;
-        __syncthreads();
-    }
-}
-
-template <typename TIn>
-__global__ __launch_bounds__(kScanThreads) void k_scan_apply(const TIn* __restrict__ in, long long nHost,
-                                                             const u64* __restrict__ dN,
-                                                             const u64* __restrict__ tileSums, u64* __restrict__ out) {
-    __shared__ u64 lds[4];
-    const long long n = dN ? (long long)*dN : nHost;
-    const long long tiles = (n + kScanTile - 1) / kScanTile;
-    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
-    for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const long long base = t * kScanTile + (long long)threadIdx.x * kScanItems;
-        u64 vals[kScanItems];
-        u64 s = 0;
-#pragma unroll
-        for (int i = 0; i < kScanItems; ++i) {
-            vals[i] = base + i < n ? (u64)in[base + i] : 0;
-            s += vals[i];
-        }
-        u64 total;
-        u64 run = tileSums[t] + block_exclusive_scan(s, lds, total);
-#pragma unroll
-        for (int i = 0; i < kScanItems; ++i) {
-            if (base + i < n) out[base + i] = run;
-            run += vals[i];
-            if (base + i == n - 1) out[n] = run;
-        }
-        __syncthreads();
-    }
-}
-
-// One workgroup scans everything: for short inputs one launch beats three.  1024 threads
-// with sixteen values each, all loaded before the first is used, so that a pass over 16384
-// values costs one memory latency.
-constexpr int kWideThreads = 1024;
-constexpr int kWideItems = 16;
-constexpr long long kSmallScanLimit = 4LL * kWideThreads * kWideItems;
-
-template <typename TIn>
-__global__ __launch_bounds__(kWideThreads) void k_scan_small(const TIn* __restrict__ in, long long nHost,
-                                                             const u64* __restrict__ dN, u64* __restrict__ out) {
-    __shared__ u64 waveTotal[kWideThreads / 64];
-    const long long n = dN ? (long long)*dN : nHost;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    u64 carry = 0;
-    for (long long base0 = 0; base0 < n; base0 += kWideThreads * kWideItems) {
-        const long long base = base0 + (long long)threadIdx.x * kWideItems;
-        u64 vals[kWideItems];
-        u64 s = 0;
-#pragma unroll
-        for (int i = 0; i < kWideItems; ++i) vals[i] = base + i < n ? (u64)in[base + i] : 0;
-#pragma unroll
-        for (int i = 0; i < kWideItems; ++i) s += vals[i];
-        const u64 inc = wave_inclusive_scan(s);
-        if (lane == 63) waveTotal[wave] = inc;
-        __syncthreads();
-        u64 before = 0, total = 0;
-#pragma unroll
-        for (int i = 0; i < kWideThreads / 64; ++i) {
-            if (i < wave) before += waveTotal[i];
-            total += waveTotal[i];
-        }
-        u64 run = carry + before + inc - s;
-#pragma unroll
-        for (int i = 0; i < kWideItems; ++i) {
-            if (base + i < n) out[base + i] = run;
-            run += vals[i];
-        }
-        carry += total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[n] = carry;
-}
-
-template <typename TIn>
-static hipError_t exclusive_scan(const TIn* in, long long nHost, const u64* dN, long long nMax, u64* tmp, u64* out,
-                                 hipStream_t s, bool haveTileSums = false) {
-    if (!haveTileSums && nMax <= kSmallScanLimit) {
-        hipLaunchKernelGGL(k_scan_small<TIn>, dim3(1), dim3(kWideThreads), 0, s, in, nHost, dN, out);
-        return hipGetLastError();
-    }
-    long long tiles = (nMax + kScanTile - 1) / kScanTile;
-    if (tiles < 1) tiles = 1;
-    const unsigned grid = (unsigned)(tiles > 1024 ? 1024 : tiles);
-    if (!haveTileSums)
-        hipLaunchKernelGGL(k_scan_tile_sums<TIn>, dim3(grid), dim3(kScanThreads), 0, s, in, nHost, dN, tmp);
-    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kScanThreads), 0, s, nHost, dN, tmp);
-    hipLaunchKernelGGL(k_scan_apply<TIn>, dim3(grid), dim3(kScanThreads), 0, s, in, nHost, dN, tmp, out);
-    return hipGetLastError();
 }
 
 // ---- restart intervals -------------------------------------------------------------------
@@ -1482,6 +1354,8 @@ __device__ __forceinline__ u32 stuff_mask(const KGeom& g, const uint8_t* __restr
 
 // One wave per 4 KiB chunk: four 16-byte pieces per lane in flight, a shuffle reduction, no
 // barriers.
+constexpr int kChunkGroup = 64;   // chunks whose counts are also kept as one sum
+
 __global__ __launch_bounds__(256) void k_count_ff(KGeom g, const uint8_t* __restrict__ buf,
                                                   const u64* __restrict__ ivOff, const u64* __restrict__ result,
                                                   u32* __restrict__ ffCount) {
@@ -1502,6 +1376,45 @@ __global__ __launch_bounds__(256) void k_count_ff(KGeom g, const uint8_t* __rest
         for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
         if (lane == 0) ffCount[ch] = (u32)cnt;
     }
+}
+
+// For long streams: the counts of kChunkGroup consecutive chunks added up, one thread per sum.
+__global__ __launch_bounds__(256) void k_group_sums(const u32* __restrict__ ffCount, const u64* __restrict__ result,
+                                                    u64* __restrict__ groupSum) {
+    const long long chunks = (long long)((result[2] + kStuffChunk - 1) / kStuffChunk);
+    const long long grp = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (grp * kChunkGroup >= chunks) return;
+    u64 sum = 0;
+    for (long long c = grp * kChunkGroup; c < (grp + 1) * kChunkGroup && c < chunks; ++c) sum += ffCount[c];
+    groupSum[grp] = sum;
+}
+
+// Stuffing bytes in front of chunk ch, added up by the 256 threads of a workgroup from the
+// per-chunk counts; cheap enough once per workgroup that the stream needs no device-wide
+// scan kernel.  Long streams (groupSum set) have the counts of whole groups added up already.
+__device__ __forceinline__ u64 chunk_prefix(const u64* __restrict__ groupSum, const u32* __restrict__ ffCount,
+                                            long long ch, u64* lds) {
+    u64 v = 0;
+    if (groupSum != nullptr) {
+        const long long grp = ch / kChunkGroup;
+        for (long long i = threadIdx.x; i < grp; i += 256) v += groupSum[i];
+        const long long c = grp * kChunkGroup + threadIdx.x;
+        if (threadIdx.x < kChunkGroup && c < ch) v += ffCount[c];
+    } else {
+        // Eight loads in flight per thread: one after the other they would cost a memory
+        // latency each.
+        for (long long i0 = threadIdx.x; i0 < ch; i0 += 8 * 256) {
+            u32 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = i0 + k * 256 < ch ? ffCount[i0 + k * 256] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += t[k];
+        }
+    }
+    u64 total;
+    block_exclusive_scan(v, lds, total);
+    __syncthreads();   // lds is free again
+    return total;
 }
 
 // Copies the stream to the output with the stuffing bytes inserted.  A workgroup's 4 KiB
@@ -1529,15 +1442,22 @@ __device__ __forceinline__ long long batch_position(const BatchOutput& bo, const
 
 template <bool kBatch>
 __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __restrict__ buf,
-                                                     const u64* __restrict__ ivOff, const u64* __restrict__ ffOff,
-                                                     u64* __restrict__ result, uint8_t* __restrict__ out,
-                                                     long long prefixLen, long long outCapacity, BatchOutput bo,
-                                                     u64* __restrict__ hostResult) {
+                                                     const u64* __restrict__ ivOff, const u32* __restrict__ ffCount,
+                                                     const u64* __restrict__ groupSum, u64* __restrict__ result,
+                                                     uint8_t* __restrict__ out, long long prefixLen,
+                                                     long long outCapacity, BatchOutput bo, u64* __restrict__ hostResult) {
     __shared__ u64 lds[4];
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStuffStageBytes];
     const u64 bytes = result[2];
     const long long chunks = (long long)((bytes + kStuffChunk - 1) / kStuffChunk);
-    for (long long ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+    // A workgroup takes a run of consecutive chunks: the stuffing bytes in front of the
+    // first come from the counting pass, those in front of the others from its own work.
+    // The runs differ by one chunk at most, so that every workgroup of the grid has work.
+    const long long chFirst = chunks * blockIdx.x / gridDim.x;
+    const long long chEnd = chunks * (blockIdx.x + 1) / gridDim.x;
+    if (chFirst >= chEnd) return;
+    u64 ffBefore = chunk_prefix(groupSum, ffCount, chFirst, lds);
+    for (long long ch = chFirst; ch < chEnd; ++ch) {
         const long long c0 = ch * kStuffChunk;
         const long long i0 = c0 + (long long)threadIdx.x * 16;
         uint4 q = make_uint4(0, 0, 0, 0);
@@ -1556,10 +1476,10 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
             const long long k = interval_of(g, ivOff, (u64)c0);
             const u64 cEnd = (u64)c0 + kStuffChunk < bytes ? (u64)c0 + kStuffChunk : bytes;
             onePiece = cEnd <= ivOff[k + 1];
-            base = batch_position(bo, ivOff, k, (u64)c0, ffOff[ch]);
+            base = batch_position(bo, ivOff, k, (u64)c0, ffBefore);
             limit = (k + 1) * bo.slotBytes;
         } else {
-            base = prefixLen + c0 + (long long)ffOff[ch];
+            base = prefixLen + c0 + (long long)ffBefore;
             limit = outCapacity;
         }
         if (onePiece) {
@@ -1600,7 +1520,7 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
             // Batch chunk across an image boundary: every byte finds its own slot.
             const u32 ws[4] = {q.x, q.y, q.z, q.w};
             long long k = interval_of(g, ivOff, (u64)i0);
-            u64 ff = ffOff[ch] + (local - (u64)((long long)i0 - c0));   // stuffing bytes in front of byte i0
+            u64 ff = ffBefore + (local - (u64)((long long)i0 - c0));   // stuffing bytes in front of byte i0
             bool overflow = false;
             for (int j = 0; j < valid; ++j) {
                 const u64 i = (u64)(i0 + j);
@@ -1621,13 +1541,16 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
             result[0] = (u64)(base + (long long)total);
             if (hostResult) hostResult[0] = (u64)(base + (long long)total);
         }
+        const u64 chunkBytes = bytes - (u64)c0 < (u64)kStuffChunk ? bytes - (u64)c0 : (u64)kStuffChunk;
+        ffBefore += total - chunkBytes;   // what the chunk wrote beyond its own bytes
         __syncthreads();
     }
 }
 
 // Batch: stuffing bytes in front of each image's stream (and, for k = batch, in total).
 __global__ __launch_bounds__(256) void k_image_ff_start(KGeom g, const uint8_t* __restrict__ buf,
-                                                        const u64* __restrict__ ivOff, const u64* __restrict__ ffOff,
+                                                        const u64* __restrict__ ivOff, const u32* __restrict__ ffCount,
+                                                        const u64* __restrict__ groupSum,
                                                         const u64* __restrict__ result, u64* __restrict__ ffStart) {
     __shared__ u64 lds[4];
     const u64 bytes = result[2];
@@ -1645,7 +1568,9 @@ __global__ __launch_bounds__(256) void k_image_ff_start(KGeom g, const uint8_t* 
     }
     u64 total;
     block_exclusive_scan((u64)cnt, lds, total);
-    if (threadIdx.x == 0) ffStart[k] = ffOff[ch] + total;
+    __syncthreads();
+    const u64 before = chunk_prefix(groupSum, ffCount, ch, lds);
+    if (threadIdx.x == 0) ffStart[k] = before + total;
 }
 
 // Batch: header k to the front of slot k.
@@ -1682,7 +1607,6 @@ __global__ __launch_bounds__(256) void k_prepare_entropy(uint4* __restrict__ str
 static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const u32* d_tables,
                                     const EntropyWorkspace& ws, uint8_t* d_out, long long prefixLen,
                                     long long outCapacity, const BatchOutput* bo, hipStream_t s) {
-    hipError_t e;
     const long long tilesPerImage = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
     const long long tileCount = tilesPerImage * g.batch;
     // The bit writer ORs into the stream, so the part it can reach starts out as zeros.
@@ -1690,6 +1614,9 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     if (zero > ws.unstuffedCap) zero = ws.unstuffedCap;
     long long prepGrid = zero / 16 / (256 * 4);
     prepGrid = prepGrid < 1 ? 1 : (prepGrid > 2048 ? 2048 : prepGrid);
+    // Chunks the stream can have at most: from the bound that was cleared.
+    long long chunkBound = zero / kStuffChunk + 1;
+    if (chunkBound > ws.maxChunks) chunkBound = ws.maxChunks;
     hipLaunchKernelGGL(k_prepare_entropy, dim3((unsigned)prepGrid), dim3(256), 0, s, (uint4*)ws.unstuffed, zero / 16,
                        ws.tileState, tileCount + 1, ws.result, ws.header, bo ? 0 : ws.headerLen, d_out,
                        bo ? nullptr : ws.pendingTables, const_cast<u32*>(d_tables));
@@ -1701,27 +1628,31 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     else
         hipLaunchKernelGGL(k_encode_bits<false>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
                            ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult);
-    // Chunks the stream can have at most: from the bound that was cleared.
-    long long chunkBound = zero / kStuffChunk + 1;
-    if (chunkBound > ws.maxChunks) chunkBound = ws.maxChunks;
     long long chunkGrid = chunkBound < 2048 ? chunkBound : 2048;
     if (chunkGrid < 1) chunkGrid = 1;
     long long countGrid = (chunkBound + 3) / 4;
     countGrid = countGrid < 1 ? 1 : (countGrid > 4096 ? 4096 : countGrid);
     hipLaunchKernelGGL(k_count_ff, dim3((unsigned)countGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.result,
                        ws.ffCount);
-    e = exclusive_scan<u32>(ws.ffCount, 0, ws.result + 3, chunkBound, ws.scanTmp, ws.ffOff, s);
-    if (e != hipSuccess) return e;
+    // Up to this many chunks a workgroup adds the counts in front of its first chunk up
+    // directly (64 loads per thread at most); beyond, group sums come first.
+    const u64* groupSum = nullptr;
+    if (chunkBound > (ws.groupSumsFrom > 0 ? ws.groupSumsFrom : 16384)) {
+        const long long groups = chunkBound / kChunkGroup + 1;
+        hipLaunchKernelGGL(k_group_sums, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, ws.ffCount, ws.result,
+                           ws.groupSum);
+        groupSum = ws.groupSum;
+    }
     if (bo) {
         hipLaunchKernelGGL(k_image_ff_start, dim3((unsigned)(g.batch + 1)), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
-                           ws.ffOff, ws.result, bo->ffStart);
+                           ws.ffCount, groupSum, ws.result, bo->ffStart);
         hipLaunchKernelGGL(k_copy_headers, dim3((unsigned)g.batch), dim3(256), 0, s, *bo);
         hipLaunchKernelGGL(k_stuff_bytes<true>, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
-                           ws.ffOff, ws.result, bo->out, 0, 0, *bo, nullptr);
+                           ws.ffCount, groupSum, ws.result, bo->out, 0, 0, *bo, nullptr);
     } else {
         BatchOutput none = {};
         hipLaunchKernelGGL(k_stuff_bytes<false>, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
-                           ws.ffOff, ws.result, d_out, prefixLen, outCapacity, none, ws.hostResult);
+                           ws.ffCount, groupSum, ws.result, d_out, prefixLen, outCapacity, none, ws.hostResult);
     }
     return hipGetLastError();
 }

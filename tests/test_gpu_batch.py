@@ -155,3 +155,20 @@ def test_device_batch_split_into_passes(ctx):
             m = ctx.encode(frames[k].data_ptr(), B.RGB8, w * 3, prm, one.data_ptr(), slot)
             assert m == int(lens[k]), (std, k)
             assert torch.equal(one[:m], out[k * slot:k * slot + m]), (std, k)
+
+
+def test_long_stream_form_of_the_stuffing_pass(ctx, monkeypatch):
+    # Streams of more than 16384 chunks (64 MiB) get the stuffing counts of 64 chunks added
+    # up by a kernel of their own; the switch lowers that limit so that small inputs take the
+    # same route: a batch with image boundaries inside chunks and a single noisy image with
+    # restart markers.
+    monkeypatch.setenv("JPEGENC_GROUP_SUMS_FROM", "2")
+    qt = T.NAMED_TABLES["ones"]
+    imgs = [synth.generate("noise", 200, 120, seed=k) for k in range(20)]
+    files, out, lens, slot = _run_batch(ctx, imgs, T.SCHEME_420, qt)
+    for k, im in enumerate(imgs):
+        assert files[k] == O.encode(im, T.SCHEME_420, qt).jpeg, k
+        assert np.all(out[k * slot + int(lens[k]):(k + 1) * slot] == 0xAA), k
+    big = synth.generate("noise", 1333, 811, seed=5)
+    prm = B.make_params(1333, 811, T.SCHEME_444, qt, restart_interval=7)
+    assert ctx.encode_host(big, prm) == O.encode(big, T.SCHEME_444, qt, restart_interval=7).jpeg
