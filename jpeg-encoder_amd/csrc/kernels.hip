@@ -1378,15 +1378,19 @@ __global__ __launch_bounds__(256) void k_count_ff(KGeom g, const uint8_t* __rest
     }
 }
 
-// For long streams: the counts of kChunkGroup consecutive chunks added up, one thread per sum.
+// For long streams: the counts of kChunkGroup consecutive chunks added up, one wave per sum.
 __global__ __launch_bounds__(256) void k_group_sums(const u32* __restrict__ ffCount, const u64* __restrict__ result,
                                                     u64* __restrict__ groupSum) {
+    static_assert(kChunkGroup == 64, "one lane per chunk of a group");
     const long long chunks = (long long)((result[2] + kStuffChunk - 1) / kStuffChunk);
-    const long long grp = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const long long grp = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (grp * kChunkGroup >= chunks) return;
-    u64 sum = 0;
-    for (long long c = grp * kChunkGroup; c < (grp + 1) * kChunkGroup && c < chunks; ++c) sum += ffCount[c];
-    groupSum[grp] = sum;
+    const long long c = grp * kChunkGroup + lane;
+    u64 sum = c < chunks ? ffCount[c] : 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane == 0) groupSum[grp] = sum;
 }
 
 // Stuffing bytes in front of chunk ch, added up by the 256 threads of a workgroup from the
@@ -1639,7 +1643,7 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     const u64* groupSum = nullptr;
     if (chunkBound > (ws.groupSumsFrom > 0 ? ws.groupSumsFrom : 16384)) {
         const long long groups = chunkBound / kChunkGroup + 1;
-        hipLaunchKernelGGL(k_group_sums, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, ws.ffCount, ws.result,
+        hipLaunchKernelGGL(k_group_sums, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, s, ws.ffCount, ws.result,
                            ws.groupSum);
         groupSum = ws.groupSum;
     }
