@@ -175,3 +175,41 @@ def test_whole_image_band_without_summed_histograms(ctx):
     ctx.histograms()
     with pytest.raises(B.JpegHipError):
         ctx.finish_band(None, d_out.data_ptr(), d_out.numel())
+
+
+def test_staged_table_sequences(ctx):
+    # Tables reach the device lazily (the first kernel of the entropy stage fetches them from
+    # pinned memory): repeated emits, tables replaced between emits, tables of one image
+    # reused for the next, and a whole-file encode in between must all see the right ones.
+    import torch
+    qt = T.quality_tables(90)
+    a = synth.generate("natural", 120, 88, seed=1)
+    b = synth.generate("noise", 120, 88, seed=2)
+    prm = B.make_params(120, 88, T.SCHEME_420, qt)
+    d_out = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    ea, eb = O.encode(a, T.SCHEME_420, qt), O.encode(b, T.SCHEME_420, qt)
+
+    def emit():
+        n = ctx.emit_scan(d_out.data_ptr(), d_out.numel())
+        return d_out[:n].cpu().numpy().tobytes()
+
+    ctx.begin(prm)
+    ctx.upload_pixels(a)
+    ctx.transform()
+    ctx.build_huffman(ctx.histograms())
+    assert emit() == ea.scan
+    assert emit() == ea.scan                       # second emit: the device copy of the tables
+    # image a under image b's tables, then back under its own
+    ctx.set_huffman(eb.lengths, eb.codes)
+    O.set_fixed_tables(eb.lengths, eb.codes)
+    try:
+        a_under_b = O.encode(a, T.SCHEME_420, qt).scan
+    finally:
+        O.set_fixed_tables()
+    assert emit() == a_under_b
+    ctx.set_huffman(ea.lengths, ea.codes)
+    assert emit() == ea.scan
+    # a whole-file encode of b installs b's tables and header; a staged emit afterwards uses them
+    assert ctx.encode_host(b, prm) == eb.jpeg
+    assert emit() == eb.scan
+    assert ctx.emit_scan_host() == eb.scan
