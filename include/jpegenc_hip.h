@@ -262,7 +262,7 @@ int jpeg_hip_finish_band(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t*
 
 /* Timing of the last jpeg_hip_encode / analyze / finish in milliseconds, measured with HIP
  * events on the context's stream: [0] fused transform kernel, [1] histogram kernel,
- * [2] entropy kernels (bit lengths, scans, bit writer, stuffing), [3] host table build.
+ * [2] entropy kernels (clears, bit writer, stuffing), [3] host table build.
  * Only filled while profiling is enabled. */
 int jpeg_hip_set_profiling(jpeg_hip_ctx* ctx, int enabled);
 int jpeg_hip_get_timings(jpeg_hip_ctx* ctx, float out_ms[4]);
