@@ -1,4 +1,6 @@
 """Randomised HIP-vs-oracle comparisons: sizes, schemes, tables, restart intervals, content mixes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -35,12 +37,17 @@ def _content(rng, w, h):
     return np.stack([g, g[:, ::-1], g * 0.5], -1).astype(np.uint8)
 
 
-@pytest.mark.parametrize("seed", range(24))
+# JPEGENC_FUZZ_SEEDS / JPEGENC_FUZZ_MAX_SIDE widen the search for an occasional long run.
+_SEEDS = int(os.environ.get("JPEGENC_FUZZ_SEEDS", "24"))
+_MAX_SIDE = int(os.environ.get("JPEGENC_FUZZ_MAX_SIDE", "400"))
+
+
+@pytest.mark.parametrize("seed", range(_SEEDS))
 def test_random_configurations_byte_identical(ctx, seed):
     rng = np.random.RandomState(1000 + seed)
     names = sorted(T.SCHEMES)
     for _ in range(6):
-        w, h = int(rng.randint(1, 400)), int(rng.randint(1, 300))
+        w, h = int(rng.randint(1, _MAX_SIDE)), int(rng.randint(1, max(2, _MAX_SIDE * 3 // 4)))
         scheme = T.SCHEMES[names[rng.randint(len(names))]]
         img = _content(rng, w, h)
         which = rng.randint(0, 4)
