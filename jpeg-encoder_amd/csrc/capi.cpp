@@ -244,6 +244,7 @@ struct jpeg_hip_ctx {
         staging, batchHdr, batchHdrLen, batchFfStart, tileState, decCoef, decPlanes, decTables, decRgb, decSum, pixelsF, pipeIn[2], pipeOut;
     jpeghip::DecodedStream* decoded = nullptr;   // last file given to the verification decoder
     WorkerPool* workers = nullptr;               // created by the first batch pass
+    WorkerPool* packers = nullptr;               // pack host frames into pinned memory (jpeg_hip_encode_batch_host)
     DevBuf histDone;                             // counter of the histogram kernel's host export
     unsigned long long histExpected = 0;         // value of that counter once every launch so far has finished
     bool histOnHost = false;                     // pin->hist holds the current band's histograms as counted
@@ -629,6 +630,7 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
                       &ctx->pipeOut, &ctx->histDone};
     delete ctx->decoded;
     delete ctx->workers;
+    delete ctx->packers;
     for (DevBuf* b : bufs) b->release();
     HostBuf* hbufs[] = {&ctx->hostHist, &ctx->hostTables, &ctx->hostHdr, &ctx->hostHdrLen, &ctx->hostOffsets,
                         &ctx->pipeStage[0], &ctx->pipeStage[1]};
@@ -1314,6 +1316,7 @@ extern "C" int jpeg_hip_encode_batch_host(jpeg_hip_ctx* ctx, const void* h_rgb, 
     }
     HIP_TRY(ctx, ctx->pipeOut.ensure((size_t)(pass * slot_bytes)));
     const int passes = (count + pass - 1) / pass;
+    if (!ctx->packers) ctx->packers = new WorkerPool(3);   // with the uploader itself: four threads pack
     std::atomic<int> uploaded(0), encoded(0), failed(0);
     std::thread uploader([&]() {
         if (hipSetDevice(ctx->device) != hipSuccess) {
@@ -1324,18 +1327,28 @@ extern "C" int jpeg_hip_encode_batch_host(jpeg_hip_ctx* ctx, const void* h_rgb, 
             while (encoded.load() < i - 1 && !failed) std::this_thread::yield();   // blocks i % 2 are free again
             const int first = i * pass, n = count - first < pass ? count - first : pass;
             uint8_t* stage = (uint8_t*)ctx->pipeStage[i & 1].p;
-            for (int k = 0; k < n; ++k) {
-                const uint8_t* src = (const uint8_t*)h_rgb + (int64_t)(first + k) * image_stride_bytes;
-                uint8_t* dst = stage + (int64_t)k * packedImage;
-                if (stride_bytes == packedStride) {
-                    memcpy(dst, src, (size_t)(packedStride * (params->height - 1) + rowBytes));
-                } else {
-                    for (int y = 0; y < params->height; ++y) memcpy(dst + y * packedStride, src + y * stride_bytes, (size_t)rowBytes);
-                }
+            // Packing a pass into pinned memory is what bounds this entry point (one thread
+            // copies about half as fast as the link transfers): several threads pack, and
+            // the pass goes up in pieces so that the link works while the next piece is packed.
+            const int pieces = n >= 8 ? 4 : 1;
+            bool sent = true;
+            for (int piece = 0; piece < pieces && sent; ++piece) {
+                const int k0 = n * piece / pieces, k1 = n * (piece + 1) / pieces;
+                ctx->packers->run(k1 - k0, [&](int t) {
+                    const int k = k0 + t;
+                    const uint8_t* src = (const uint8_t*)h_rgb + (int64_t)(first + k) * image_stride_bytes;
+                    uint8_t* dst = stage + (int64_t)k * packedImage;
+                    if (stride_bytes == packedStride) {
+                        memcpy(dst, src, (size_t)(packedStride * (params->height - 1) + rowBytes));
+                    } else {
+                        for (int y = 0; y < params->height; ++y)
+                            memcpy(dst + y * packedStride, src + y * stride_bytes, (size_t)rowBytes);
+                    }
+                });
+                sent = hipMemcpyAsync((uint8_t*)ctx->pipeIn[i & 1].p + (int64_t)k0 * packedImage, stage + (int64_t)k0 * packedImage,
+                                      (size_t)((k1 - k0) * packedImage), hipMemcpyHostToDevice, ctx->copyStream) == hipSuccess;
             }
-            if (hipMemcpyAsync(ctx->pipeIn[i & 1].p, stage, (size_t)(n * packedImage), hipMemcpyHostToDevice,
-                               ctx->copyStream) != hipSuccess ||
-                hipEventRecord(ctx->pipeEvent[i & 1], ctx->copyStream) != hipSuccess) {
+            if (!sent || hipEventRecord(ctx->pipeEvent[i & 1], ctx->copyStream) != hipSuccess) {
                 failed = 1;
                 return;
             }
