@@ -269,7 +269,7 @@ class Context:
         if stride is None:
             stride = rgb.strides[0]
         lay = compute_layout(params)
-        out = np.zeros(int(lay.max_jpeg_bytes), np.uint8)
+        out = np.empty(int(lay.max_jpeg_bytes), np.uint8)   # worst case: large, so not cleared
         n = C.c_int64(0)
         self._check(lib().jpeg_hip_encode_host(self._h, _np(rgb), fmt, stride, C.byref(params), _np(out), out.size,
                                                C.byref(n)))
