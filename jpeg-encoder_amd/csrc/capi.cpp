@@ -247,6 +247,7 @@ struct jpeg_hip_ctx {
     WorkerPool* packers = nullptr;               // pack host pixels into pinned memory (uploads, jpeg_hip_encode_batch_host)
     HostBuf uploadStage[2];                      // pinned blocks jpeg_hip_upload_pixels sends its pieces from
     hipEvent_t uploadEvent[2] = {nullptr, nullptr};
+    DevBuf gather;                               // one channel's coefficients, contiguous (jpeg_hip_get_coefficients)
     DevBuf histDone;                             // counter of the histogram kernel's host export
     unsigned long long histExpected = 0;         // value of that counter once every launch so far has finished
     bool histOnHost = false;                     // pin->hist holds the current band's histograms as counted
@@ -629,7 +630,7 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->groupSum, &ctx->result,
                       &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart,
                       &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum, &ctx->pixelsF, &ctx->pipeIn[0], &ctx->pipeIn[1],
-                      &ctx->pipeOut, &ctx->histDone};
+                      &ctx->pipeOut, &ctx->histDone, &ctx->gather};
     delete ctx->decoded;
     delete ctx->workers;
     delete ctx->packers;
@@ -946,10 +947,14 @@ int jpeg_hip_get_coefficients(jpeg_hip_ctx* ctx, int channel, int16_t* h_out, in
     const Geometry& g = ctx->geo;
     const int64_t perMcu = g.chanBlocks[channel];
     if (capacity_values < g.nMcu * perMcu * 64) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "coefficient buffer too small");
-    // Scan order interleaves the channels per MCU; copy this channel's slices out.
-    HIP_TRY(ctx, hipMemcpy2DAsync(h_out, (size_t)perMcu * 128, (const char*)ctx->coef.p + (size_t)g.chanOffset[channel] * 128,
+    // Scan order interleaves the channels per MCU: this channel's slices are gathered on the
+    // device and leave in one piece (a strided copy to pageable memory goes row by row).
+    const size_t bytes = (size_t)g.nMcu * perMcu * 128;
+    HIP_TRY(ctx, ctx->gather.ensure(bytes));
+    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->gather.p, (size_t)perMcu * 128, (const char*)ctx->coef.p + (size_t)g.chanOffset[channel] * 128,
                                   (size_t)g.blocksPerMcu * 128, (size_t)perMcu * 128, (size_t)g.nMcu,
-                                  hipMemcpyDeviceToHost, ctx->stream));
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h_out, ctx->gather.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, wait_stream(ctx));
     return JPEG_HIP_OK;
 }
