@@ -3,7 +3,8 @@
 //   encode_jpeg <source .ppm/.png> <destination .jpg> [444|422|411|420] [quality 1..100 | 0 = Annex K tables]
 //               [options: sepia, gain=<channel 0..2>:<factor> (on R, G, B),
 //                ycbcr-gain=<channel>:<factor> (after convertToYCbCr), reduced-gain=<channel>:<factor>
-//                (after reduceResolutionBySchema), standard-huffman, restart=<MCUs>]
+//                (after reduceResolutionBySchema), standard-huffman, restart=<MCUs>, timing]
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -13,19 +14,27 @@
 #include "ImageLoader.h"
 
 struct Options {
-    bool sepia = false, standardHuffman = false;
+    bool sepia = false, standardHuffman = false, timing = false;
     int gainChannel = -1, ycbcrGainChannel = -1, reducedGainChannel = -1, restart = 0;
     float gain = 1.0f, ycbcrGain = 1.0f, reducedGain = 1.0f;
 };
 
 static void EncodeJPEG(const std::string& srcFile, const std::string& dstFile, const SamplingDefinition& scheme,
                        const QTableSet& qtables, const Options& opt) {
+    auto last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {   // the reference's driver prints such a line per step (JPEG-Encoder-SIMD.cpp:401-437)
+        const auto now = std::chrono::steady_clock::now();
+        if (opt.timing) std::cerr << what << ": " << std::chrono::duration<double, std::milli>(now - last).count() << " ms" << std::endl;
+        last = now;
+    };
     ImagePtr image = ImageLoader::Load(srcFile, scheme);
+    lap("load");
     if (!image) {
         std::cout << "Failed to load source image " << srcFile << std::endl;
         exit(2);
     }
     EncoderPtr encoder = std::make_shared<Encoder>(image, qtables);
+    lap("encoder (device context)");
     if (opt.sepia) encoder->applySepia();
     if (opt.gainChannel >= 0) encoder->multiplyColorChannelBy((ColorChannelName)opt.gainChannel, opt.gain);
     encoder->setStandardHuffmanTables(opt.standardHuffman);
@@ -38,7 +47,9 @@ static void EncodeJPEG(const std::string& srcFile, const std::string& dstFile, c
     encoder->applyDCT(YCbCrColorName::Y);
     encoder->applyDCT(YCbCrColorName::Cb);
     encoder->applyDCT(YCbCrColorName::Cr);
+    lap("convert, reduce, transform");
     ImageLoader::Save(dstFile, encoder);
+    lap("tables, scan, file");
 }
 
 int main(int argc, char* argv[]) {
@@ -56,6 +67,7 @@ int main(int argc, char* argv[]) {
         const std::string a = argv[i];
         if (a == "sepia") opt.sepia = true;
         else if (a == "standard-huffman") opt.standardHuffman = true;
+        else if (a == "timing") opt.timing = true;
         else if (a.rfind("restart=", 0) == 0) opt.restart = atoi(a.c_str() + 8);
         else if (a.rfind("gain=", 0) == 0 && a.size() > 7 && a[6] == ':') {
             opt.gainChannel = a[5] - '0';

@@ -220,8 +220,16 @@ static size_t roundUp(size_t v, size_t step) { return (v + step - 1) / step * st
 Image::Image(size_t width, size_t height, SamplingDefinition scheme)
     : imageSize(width, height),
       simulatedSize(roundUp(width, scheme.stepSize.width), roundUp(height, scheme.stepSize.height)),
-      samplingScheme(scheme),
-      pixels(width * height * 3, 0.0f) {}
+      samplingScheme(scheme) {}
+
+std::vector<float>& Image::floats() const {
+    const size_t n = imageSize.width * imageSize.height * 3;
+    if (pixels.size() != n) {
+        pixels.assign(n, 0.0f);   // a new image is black
+        for (size_t i = 0; i < pixels8.size(); ++i) pixels[i] = pixels8[i] / 255.0f;   // ImageLoader.cpp:190-193
+    }
+    return pixels;
+}
 
 void Image::setRawPixelData(float* rgb) {
     pixels8.clear();
@@ -230,8 +238,7 @@ void Image::setRawPixelData(float* rgb) {
 
 void Image::setRawPixelData8(const byte* rgb) {
     pixels8.assign(rgb, rgb + imageSize.width * imageSize.height * 3);
-    pixels.resize(pixels8.size());
-    for (size_t i = 0; i < pixels8.size(); ++i) pixels[i] = pixels8[i] / 255.0f;   // ImageLoader.cpp:190-193
+    std::vector<float>().swap(pixels);
 }
 
 size_t Image::clampedIndex(size_t x, size_t y) const {
@@ -242,6 +249,13 @@ size_t Image::clampedIndex(size_t x, size_t y) const {
 
 void Image::getPixel(PixelData32& ref, size_t x, size_t y) const {
     const size_t i = clampedIndex(x, y);
+    if (!pixels8.empty()) {
+        ref.R = pixels8[i] / 255.0f;
+        ref.G = pixels8[i + 1] / 255.0f;
+        ref.B = pixels8[i + 2] / 255.0f;
+        return;
+    }
+    const std::vector<float>& pixels = floats();
     ref.R = pixels[i];
     ref.G = pixels[i + 1];
     ref.B = pixels[i + 2];
@@ -250,6 +264,7 @@ void Image::getPixel(PixelData32& ref, size_t x, size_t y) const {
 void Image::setPixel(size_t x, size_t y, const PixelData32& c) {
     if (x >= imageSize.width || y >= imageSize.height) return;
     const size_t i = clampedIndex(x, y);
+    std::vector<float>& pixels = floats();
     pixels[i] = c.R;
     pixels[i + 1] = c.G;
     pixels[i + 2] = c.B;
@@ -257,6 +272,7 @@ void Image::setPixel(size_t x, size_t y, const PixelData32& c) {
 }
 
 void Image::applySepia() {
+    std::vector<float>& pixels = floats();
     for (size_t i = 0; i + 2 < pixels.size(); i += 3) {
         const float r = pixels[i], g = pixels[i + 1], b = pixels[i + 2];
         float t = 0.3930f * r;
@@ -277,12 +293,14 @@ void Image::applySepia() {
 
 std::vector<float> Image::getRawPixelData() {
     std::vector<float> out(imageSize.width * imageSize.height * 4);   // sized as the reference does; 3 used per pixel
+    const std::vector<float>& pixels = floats();
     std::copy(pixels.begin(), pixels.end(), out.begin());
     return out;
 }
 
 std::vector<float> Image::getRawPixelDataSimulated() {
     std::vector<float> out(simulatedSize.width * simulatedSize.height * 4);
+    const std::vector<float>& pixels = floats();
     size_t o = 0;
     for (size_t y = 0; y < simulatedSize.height; ++y)
         for (size_t x = 0; x < simulatedSize.width; ++x) {
@@ -353,7 +371,7 @@ void Encoder::ensureTransformed() {
         check(jpeg_hip_upload_pixels(ctx, image->pixels8.data(), JPEG_HIP_RGB8, (int64_t)image->imageSize.width * 3),
               "jpeg_hip_upload_pixels");
     else
-        check(jpeg_hip_upload_pixels(ctx, image->pixels.data(), JPEG_HIP_RGBF32,
+        check(jpeg_hip_upload_pixels(ctx, image->floats().data(), JPEG_HIP_RGBF32,
                                      (int64_t)image->imageSize.width * 3 * sizeof(float)),
               "jpeg_hip_upload_pixels");
     for (const PixelOp& op : pixelOps)
@@ -494,18 +512,25 @@ ImagePtr ImageLoader::LoadPPM(std::string path, SamplingDefinition scheme) {
         return nullptr;
     }
     const size_t n = (size_t)width * height * 3;
+    ImagePtr image = std::make_shared<Image>((size_t)width, (size_t)height, scheme);
+    if (!ascii && maxValue == 255) {   // the common case in one read: bytes as they are
+        in.get();   // the single white-space byte after maxval
+        std::vector<byte> bytes(n, 0);
+        in.read(reinterpret_cast<char*>(bytes.data()), (std::streamsize)n);
+        image->setRawPixelData8(bytes.data());
+        return image;
+    }
     std::vector<int> samples(n, 0);
     if (ascii) {
         for (size_t i = 0; i < n && nextToken(in, tok); ++i) samples[i] = atoi(tok.c_str());
     } else {
-        in.get();   // the single white-space byte after maxval
+        in.get();
         for (size_t i = 0; i < n; ++i) {
             int v = in.get();
             if (maxValue > 255) v = (v << 8) | in.get();
             samples[i] = v < 0 ? 0 : v;
         }
     }
-    ImagePtr image = std::make_shared<Image>((size_t)width, (size_t)height, scheme);
     if (maxValue == 255) {   // same arithmetic as value / 255.0f, done on the GPU
         std::vector<byte> bytes(n);
         for (size_t i = 0; i < n; ++i) bytes[i] = (byte)samples[i];
@@ -539,8 +564,13 @@ void ImageLoader::SavePPM(std::string path, ImagePtr image) {
 static uint32_t be32(const byte* p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
 
 ImagePtr ImageLoader::LoadPNG(std::string path, SamplingDefinition scheme) {
-    std::ifstream in(path, std::ios::binary);
-    std::vector<byte> file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    std::ifstream in(path, std::ios::binary | std::ios::ate);
+    std::vector<byte> file;
+    if (in.is_open()) {
+        file.resize((size_t)in.tellg());
+        in.seekg(0);
+        in.read(reinterpret_cast<char*>(file.data()), (std::streamsize)file.size());
+    }
     static const byte sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (file.size() < 8 || memcmp(file.data(), sig, 8) != 0) {
         std::cout << "Failed to decode png " << path << ": not a PNG file" << std::endl;
@@ -581,33 +611,47 @@ ImagePtr ImageLoader::LoadPNG(std::string path, SamplingDefinition scheme) {
         std::cout << "Failed to decode png " << path << ": inflate error" << std::endl;
         return nullptr;
     }
-    std::vector<byte> cur(stride), prev(stride, 0), rgb((size_t)width * height * 3);
+    // Undo the line filters in place (one loop per filter type), then bring the samples to RGB.
+    std::vector<byte> zero(stride, 0), rgb((size_t)width * height * 3);
+    const size_t bpp = (size_t)channels;
     for (uint32_t y = 0; y < height; ++y) {
-        const byte* line = &raw[(stride + 1) * y];
-        const int filter = line[0];
-        for (size_t i = 0; i < stride; ++i) {
-            const int a = i >= (size_t)channels ? cur[i - channels] : 0, b = prev[i];
-            const int c = i >= (size_t)channels ? prev[i - channels] : 0;
-            int pred = 0;
-            if (filter == 1) pred = a;
-            else if (filter == 2) pred = b;
-            else if (filter == 3) pred = (a + b) >> 1;
-            else if (filter == 4) {
+        byte* cur = &raw[(stride + 1) * y + 1];
+        const byte* prev = y > 0 ? &raw[(stride + 1) * (y - 1) + 1] : zero.data();
+        switch (cur[-1]) {
+        case 1:
+            for (size_t i = bpp; i < stride; ++i) cur[i] = (byte)(cur[i] + cur[i - bpp]);
+            break;
+        case 2:
+            for (size_t i = 0; i < stride; ++i) cur[i] = (byte)(cur[i] + prev[i]);
+            break;
+        case 3:
+            for (size_t i = 0; i < bpp; ++i) cur[i] = (byte)(cur[i] + (prev[i] >> 1));
+            for (size_t i = bpp; i < stride; ++i) cur[i] = (byte)(cur[i] + ((cur[i - bpp] + prev[i]) >> 1));
+            break;
+        case 4:
+            for (size_t i = 0; i < bpp; ++i) cur[i] = (byte)(cur[i] + prev[i]);   // a = c = 0: the predictor is b
+            for (size_t i = bpp; i < stride; ++i) {
+                const int a = cur[i - bpp], b = prev[i], c = prev[i - bpp];
                 const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
-                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                cur[i] = (byte)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)));
             }
-            cur[i] = (byte)(line[1 + i] + pred);
+            break;
+        default:
+            break;
         }
-        for (uint32_t x = 0; x < width; ++x) {
-            byte* o = &rgb[((size_t)y * width + x) * 3];
-            const byte* s = &cur[(size_t)x * channels];
-            if (colour == 2 || colour == 6) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; }
-            else if (colour == 3) {
-                const size_t pi = (size_t)s[0] * 3;
-                for (int k = 0; k < 3; ++k) o[k] = pi + k < palette.size() ? palette[pi + k] : 0;
-            } else { o[0] = o[1] = o[2] = s[0]; }
+        byte* o = &rgb[(size_t)y * width * 3];
+        if (colour == 2) {
+            memcpy(o, cur, (size_t)width * 3);
+        } else {
+            for (uint32_t x = 0; x < width; ++x, o += 3) {
+                const byte* s = &cur[(size_t)x * channels];
+                if (colour == 6) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; }
+                else if (colour == 3) {
+                    const size_t pi = (size_t)s[0] * 3;
+                    for (int k = 0; k < 3; ++k) o[k] = pi + k < palette.size() ? palette[pi + k] : 0;
+                } else { o[0] = o[1] = o[2] = s[0]; }
+            }
         }
-        prev.swap(cur);
     }
     ImagePtr image = std::make_shared<Image>((size_t)width, (size_t)height, scheme);
     image->setRawPixelData8(rgb.data());

@@ -218,9 +218,13 @@ class Image {
     const Dimension2D imageSize;
     const Dimension2D simulatedSize;  // padded to whole MCUs
     const SamplingDefinition samplingScheme;
-    std::vector<float> pixels;        // interleaved RGB in [0,1], real size
-    std::vector<byte> pixels8;        // interleaved RGB bytes when the image was set from bytes
+    // Interleaved RGB, real size.  An image set from bytes keeps the bytes (the encoder sends
+    // those and the GPU divides by 255.0f); the floats in [0,1] are made when somebody asks
+    // for them.  Anything that changes a pixel works on the floats and drops the bytes.
+    mutable std::vector<float> pixels;
+    std::vector<byte> pixels8;
     size_t clampedIndex(size_t x, size_t y) const;
+    std::vector<float>& floats() const;
 
 public:
     Image(size_t width, size_t height, SamplingDefinition scheme);
