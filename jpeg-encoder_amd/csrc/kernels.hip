@@ -624,6 +624,156 @@ hipError_t launch_pixel_filter(const void* d_src, int sampleFormat, long long sr
     return hipGetLastError();
 }
 
+// ----------------------------------------------------------------------------------------
+// Row-wise transform for the remaining schemes (4:2:2, 4:1:1, the averaging and the
+// height-reducing variants) on byte pixels: one thread per 8x8 block like the generic
+// kernel, but the source pixels come in as 24-byte rows (load_row8, which also does the
+// edge replication), samples go straight to registers, and a wave's 64 blocks leave
+// through the store stage in whole lines.  The reduction follows Encoder.cpp:40-155: across
+// first, then down; "Average" sums left to right (top to bottom) and divides by the factor,
+// "Subsampling" keeps the first pixel of each group.
+// ----------------------------------------------------------------------------------------
+template <int WF, int NH>
+__device__ __forceinline__ void gather_block_rows(const KGeom& g, const unsigned char* __restrict__ pix, int sx0, int sy0,
+                                                  int hf, int nw, bool interior, int c, f2 (&a)[32]) {
+    // For groups of up to four source pixels: as many sample rows at a time as 48 registers of
+    // source pixels hold, their loads all issued before the first is used.
+    constexpr int kRows = 8 / (WF * NH) > 0 ? 8 / (WF * NH) : 1;
+#pragma unroll
+    for (int r0 = 0; r0 < 8; r0 += kRows) {
+        u32 raw[kRows][NH][WF][6];
+#pragma unroll
+        for (int rr = 0; rr < kRows; ++rr)
+#pragma unroll
+            for (int dy = 0; dy < NH; ++dy)
+#pragma unroll
+                for (int sgm = 0; sgm < WF; ++sgm)
+                    load_row8(pix, g.strideBytes, sx0 + 8 * sgm, sy0 + (r0 + rr) * hf + dy, interior, g.W, g.rowsAvail,
+                              raw[rr][dy][sgm]);
+#pragma unroll
+        for (int rr = 0; rr < kRows; ++rr) {
+            const int r = r0 + rr;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float vsum = 0.0f;
+#pragma unroll
+                for (int dy = 0; dy < NH; ++dy) {
+                    float hsum = 0.0f;
+#pragma unroll
+                    for (int dx = 0; dx < WF; ++dx) {
+                        if (dx < nw) {
+                            const int px = i * WF + dx, sgm = px >> 3, j = px & 7;
+                            const float rd = unorm8(raw[rr][dy][sgm][(3 * j) >> 2], (3 * j) & 3);
+                            const float gn = unorm8(raw[rr][dy][sgm][(3 * j + 1) >> 2], (3 * j + 1) & 3);
+                            const float bl = unorm8(raw[rr][dy][sgm][(3 * j + 2) >> 2], (3 * j + 2) & 3);
+                            const float v = channel_value(c, true, rd, gn, bl);
+                            hsum = dx == 0 ? v : hsum + v;
+                        }
+                    }
+                    const float hval = nw > 1 ? hsum / (float)WF : hsum;
+                    vsum = dy == 0 ? hval : vsum + hval;
+                }
+                const float val = NH > 1 ? vsum / (float)NH : vsum;
+                if (r & 1) a[(r >> 1) * 8 + i].y = val;
+                else a[(r >> 1) * 8 + i].x = val;
+            }
+        }
+    }
+}
+
+// The deep groups (eight or more source pixels per sample): one sample row at a time, the rows
+// of a group in a loop that is not unrolled, which keeps the code within the instruction cache.
+template <int WF>
+__device__ __forceinline__ void gather_block_rows_deep(const KGeom& g, const unsigned char* __restrict__ pix, int sx0,
+                                                       int sy0, int hf, int nw, int nh, bool interior, int c, f2 (&a)[32]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float vsum[8];
+#pragma unroll 1
+        for (int dy = 0; dy < nh; ++dy) {
+            u32 raw[WF][6];
+#pragma unroll
+            for (int sgm = 0; sgm < WF; ++sgm)
+                load_row8(pix, g.strideBytes, sx0 + 8 * sgm, sy0 + r * hf + dy, interior, g.W, g.rowsAvail, raw[sgm]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float hsum = 0.0f;
+#pragma unroll
+                for (int dx = 0; dx < WF; ++dx) {
+                    if (dx < nw) {
+                        const int px = i * WF + dx, sgm = px >> 3, j = px & 7;
+                        const float rd = unorm8(raw[sgm][(3 * j) >> 2], (3 * j) & 3);
+                        const float gn = unorm8(raw[sgm][(3 * j + 1) >> 2], (3 * j + 1) & 3);
+                        const float bl = unorm8(raw[sgm][(3 * j + 2) >> 2], (3 * j + 2) & 3);
+                        const float v = channel_value(c, true, rd, gn, bl);
+                        hsum = dx == 0 ? v : hsum + v;
+                    }
+                }
+                const float hval = nw > 1 ? hsum / (float)WF : hsum;
+                vsum[i] = dy == 0 ? hval : vsum[i] + hval;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float val = nh > 1 ? vsum[i] / (float)nh : vsum[i];
+            if (r & 1) a[(r >> 1) * 8 + i].y = val;
+            else a[(r >> 1) * 8 + i].x = val;
+        }
+    }
+}
+
+template <int WF>
+__device__ __forceinline__ void gather_block_rows(const KGeom& g, const unsigned char* __restrict__ pix, int sx0, int sy0,
+                                                  int hf, int nw, int nh, bool interior, int c, f2 (&a)[32]) {
+    if (nh == 1) gather_block_rows<WF, 1>(g, pix, sx0, sy0, hf, nw, interior, c, a);
+    else if (WF * 2 <= 4 && nh == 2) gather_block_rows<WF, (WF * 2 <= 4 ? 2 : 1)>(g, pix, sx0, sy0, hf, nw, interior, c, a);
+    else if (WF == 1 && nh == 4) gather_block_rows<WF, (WF == 1 ? 4 : 1)>(g, pix, sx0, sy0, hf, nw, interior, c, a);
+    else gather_block_rows_deep<WF>(g, pix, sx0, sy0, hf, nw, nh, interior, c, a);
+}
+
+// A workgroup takes 64 MCUs, wave j block j of each of them: channel and factors are the
+// same for a whole wave (no divergence between luma and chroma lanes), and lane l's block
+// lies bpm blocks behind lane l - 1's, which is what the store stage expects.
+constexpr int kRowsMaxBpm = 8;
+
+__global__ __launch_bounds__(64 * kRowsMaxBpm) void k_transform_rows(KGeom g, const unsigned char* __restrict__ rgb,
+                                                                     const float* __restrict__ qtab,
+                                                                     int16_t* __restrict__ coef, u64* __restrict__ clearHist) {
+    clear_histograms(clearHist);
+    __shared__ __attribute__((aligned(16))) unsigned char stage[kRowsMaxBpm * 32 * kStagePitch];
+    const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // block inside the MCU
+    const int lane = threadIdx.x & 63;
+    const long long mBase = (long long)blockIdx.x * 64;
+    const long long left = g.nMcu - mBase;
+    const int count = left < 64 ? (int)left : 64;
+    const long long m = mBase + (lane < count ? lane : count - 1);   // idle lanes redo the last MCU, store nothing
+    int c, bx, by;
+    block_in_mcu(g, k, c, bx, by);
+    int mx, my;
+    const unsigned char* pix = rgb + locate_mcu(g, m, mx, my);
+    const int wf = g.wf[c], hf = g.hf[c];
+    const int nw = g.wm[c] == JPEG_HIP_AVERAGE ? wf : 1;
+    const int nh = g.hm[c] == JPEG_HIP_AVERAGE ? hf : 1;
+    const int sx0 = (mx * g.hF[c] + bx) * 8 * wf, sy0 = (my * g.vF[c] + by) * 8 * hf;
+    // With "Subsampling" only the first row and column of each group are read, but a block
+    // that reaches past the image in the unread ones is treated as an edge block all the same.
+    const bool interior = sx0 + 8 * wf <= g.W && sy0 + 8 * hf <= g.rowsAvail;
+    f2 a[32];
+    if (wf == 1) gather_block_rows<1>(g, pix, sx0, sy0, hf, nw, nh, interior, c, a);
+    else if (wf == 2) gather_block_rows<2>(g, pix, sx0, sy0, hf, nw, nh, interior, c, a);
+    else gather_block_rows<4>(g, pix, sx0, sy0, hf, nw, nh, interior, c, a);
+    finish_block_staged<2>(a, qtab + 192 + 64 * c, qtab + 384 + 64 * c, stage + k * 32 * kStagePitch,
+                           coef + (mBase * g.bpm + k) * 64, g.bpm, count);
+}
+
+// The row-wise kernel takes factors 1, 2 and 4 and up to eight blocks per MCU (every scheme
+// of the reference).
+static bool rows_kernel_takes(const KGeom& g) {
+    for (int c = 0; c < 3; ++c)
+        if (g.wf[c] == 3 || g.hf[c] == 3) return false;
+    return g.bpm <= kRowsMaxBpm;
+}
+
 static bool scheme_is(const KGeom& g, int wf, int hf, int method) {
     if (g.wf[0] != 1 || g.hf[0] != 1) return false;
     for (int c = 1; c < 3; ++c) {
@@ -647,6 +797,10 @@ hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qt
         const long long grid = (g.nMcu + k444Positions - 1) / k444Positions;
         hipLaunchKernelGGL(k_transform_444, dim3((unsigned)grid), dim3(3 * k444Positions), 0, s, g,
                            (const unsigned char*)d_rgb, d_qtab, d_coef, d_clearHist);
+    } else if (bytesAligned && rows_kernel_takes(g)) {
+        const long long grid = (g.nMcu + 63) / 64;
+        hipLaunchKernelGGL(k_transform_rows, dim3((unsigned)grid), dim3(64 * g.bpm), 0, s, g, (const unsigned char*)d_rgb, d_qtab, d_coef,
+                           d_clearHist);
     } else {
         const long long grid = (g.totalBlocks + kGenThreads - 1) / kGenThreads;
         hipLaunchKernelGGL(k_transform_generic, dim3((unsigned)grid), dim3(kGenThreads), 0, s, g, d_rgb, d_qtab, d_coef,
