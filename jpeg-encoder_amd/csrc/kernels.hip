@@ -731,11 +731,74 @@ __device__ __forceinline__ void gather_block_rows(const KGeom& g, const unsigned
     else gather_block_rows_deep<WF>(g, pix, sx0, sy0, hf, nw, nh, interior, c, a);
 }
 
+// Float pixels (Image::setRawPixelData, values already in 0..1): eight pixels are 96 bytes,
+// six 16-byte reads when rows start on 16-byte boundaries, single floats otherwise and at
+// the image edge.
+__device__ __forceinline__ void load_row8f(const unsigned char* __restrict__ rgb, long long stride, int x0, int y,
+                                           bool fast, int W, int rows, float (&raw)[24]) {
+    if (fast) {
+        const float4* p = (const float4*)(rgb + (long long)y * stride + (long long)x0 * 12);
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+            const float4 v = p[d];
+            raw[4 * d] = v.x; raw[4 * d + 1] = v.y; raw[4 * d + 2] = v.z; raw[4 * d + 3] = v.w;
+        }
+    } else {
+        const unsigned char* row = rgb + (long long)min(y, rows - 1) * stride;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float* px = (const float*)(row + (long long)min(x0 + i, W - 1) * 12);
+            raw[3 * i] = px[0]; raw[3 * i + 1] = px[1]; raw[3 * i + 2] = px[2];
+        }
+    }
+}
+
+template <int WF>
+__device__ __forceinline__ void gather_block_rows_f32(const KGeom& g, const unsigned char* __restrict__ pix, int sx0,
+                                                      int sy0, int hf, int nw, int nh, bool fast, int c, bool convert,
+                                                      f2 (&a)[32]) {
+    constexpr int kPer = 8 / WF;   // samples that one 8-pixel segment yields
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float vsum[8];
+#pragma unroll 1
+        for (int dy = 0; dy < nh; ++dy) {
+#pragma unroll
+            for (int sgm = 0; sgm < WF; ++sgm) {
+                float raw[24];
+                load_row8f(pix, g.strideBytes, sx0 + 8 * sgm, sy0 + r * hf + dy, fast, g.W, g.rowsAvail, raw);
+#pragma unroll
+                for (int ii = 0; ii < kPer; ++ii) {
+                    const int i = sgm * kPer + ii;
+                    float hsum = 0.0f;
+#pragma unroll
+                    for (int dx = 0; dx < WF; ++dx) {
+                        if (dx < nw) {
+                            const int j = ii * WF + dx;
+                            const float v = channel_value(c, convert, raw[3 * j], raw[3 * j + 1], raw[3 * j + 2]);
+                            hsum = dx == 0 ? v : hsum + v;
+                        }
+                    }
+                    const float hval = nw > 1 ? hsum / (float)WF : hsum;
+                    vsum[i] = dy == 0 ? hval : vsum[i] + hval;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float val = nh > 1 ? vsum[i] / (float)nh : vsum[i];
+            if (r & 1) a[(r >> 1) * 8 + i].y = val;
+            else a[(r >> 1) * 8 + i].x = val;
+        }
+    }
+}
+
 // A workgroup takes 64 MCUs, wave j block j of each of them: channel and factors are the
 // same for a whole wave (no divergence between luma and chroma lanes), and lane l's block
 // lies bpm blocks behind lane l - 1's, which is what the store stage expects.
 constexpr int kRowsMaxBpm = 8;
 
+template <bool kFloat>
 __global__ __launch_bounds__(64 * kRowsMaxBpm) void k_transform_rows(KGeom g, const unsigned char* __restrict__ rgb,
                                                                      const float* __restrict__ qtab,
                                                                      int16_t* __restrict__ coef, u64* __restrict__ clearHist) {
@@ -759,9 +822,17 @@ __global__ __launch_bounds__(64 * kRowsMaxBpm) void k_transform_rows(KGeom g, co
     // that reaches past the image in the unread ones is treated as an edge block all the same.
     const bool interior = sx0 + 8 * wf <= g.W && sy0 + 8 * hf <= g.rowsAvail;
     f2 a[32];
-    if (wf == 1) gather_block_rows<1>(g, pix, sx0, sy0, hf, nw, nh, interior, c, a);
-    else if (wf == 2) gather_block_rows<2>(g, pix, sx0, sy0, hf, nw, nh, interior, c, a);
-    else gather_block_rows<4>(g, pix, sx0, sy0, hf, nw, nh, interior, c, a);
+    if (kFloat) {
+        const bool convert = (g.stages & JPEG_HIP_STAGE_YCBCR) != 0;
+        const bool fast = interior && (((uintptr_t)rgb | (uintptr_t)g.strideBytes | (uintptr_t)g.imageStrideBytes) & 15) == 0;
+        if (wf == 1) gather_block_rows_f32<1>(g, pix, sx0, sy0, hf, nw, nh, fast, c, convert, a);
+        else if (wf == 2) gather_block_rows_f32<2>(g, pix, sx0, sy0, hf, nw, nh, fast, c, convert, a);
+        else gather_block_rows_f32<4>(g, pix, sx0, sy0, hf, nw, nh, fast, c, convert, a);
+    } else {
+        if (wf == 1) gather_block_rows<1>(g, pix, sx0, sy0, hf, nw, nh, interior, c, a);
+        else if (wf == 2) gather_block_rows<2>(g, pix, sx0, sy0, hf, nw, nh, interior, c, a);
+        else gather_block_rows<4>(g, pix, sx0, sy0, hf, nw, nh, interior, c, a);
+    }
     finish_block_staged<2>(a, qtab + 192 + 64 * c, qtab + 384 + 64 * c, stage + k * 32 * kStagePitch,
                            coef + (mBase * g.bpm + k) * 64, g.bpm, count);
 }
@@ -799,8 +870,12 @@ hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qt
                            (const unsigned char*)d_rgb, d_qtab, d_coef, d_clearHist);
     } else if (bytesAligned && rows_kernel_takes(g)) {
         const long long grid = (g.nMcu + 63) / 64;
-        hipLaunchKernelGGL(k_transform_rows, dim3((unsigned)grid), dim3(64 * g.bpm), 0, s, g, (const unsigned char*)d_rgb, d_qtab, d_coef,
-                           d_clearHist);
+        hipLaunchKernelGGL(k_transform_rows<false>, dim3((unsigned)grid), dim3(64 * g.bpm), 0, s, g,
+                           (const unsigned char*)d_rgb, d_qtab, d_coef, d_clearHist);
+    } else if (g.sampleFormat == JPEG_HIP_RGBF32 && g.nGains == 0 && rows_kernel_takes(g)) {   // any stages, any scheme
+        const long long grid = (g.nMcu + 63) / 64;
+        hipLaunchKernelGGL(k_transform_rows<true>, dim3((unsigned)grid), dim3(64 * g.bpm), 0, s, g,
+                           (const unsigned char*)d_rgb, d_qtab, d_coef, d_clearHist);
     } else {
         const long long grid = (g.totalBlocks + kGenThreads - 1) / kGenThreads;
         hipLaunchKernelGGL(k_transform_generic, dim3((unsigned)grid), dim3(kGenThreads), 0, s, g, d_rgb, d_qtab, d_coef,

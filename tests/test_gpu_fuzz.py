@@ -90,3 +90,24 @@ def test_extreme_aspect_ratios(ctx):
             want = O.encode(img, T.SCHEMES[scheme], qt).jpeg
             got = ctx.encode_host(img, B.make_params(w, h, T.SCHEMES[scheme], qt))
             assert got == want, (w, h, scheme)
+
+
+@pytest.mark.parametrize("seed", range(max(4, _SEEDS // 4)))
+def test_random_configurations_float_pixels(ctx, seed):
+    # Float pixels (Image::setRawPixelData) take a path of their own through the transform:
+    # arbitrary values in 0..1, every scheme, aligned and unaligned row lengths.
+    rng = np.random.RandomState(5000 + seed)
+    names = sorted(T.SCHEMES)
+    for _ in range(6):
+        w, h = int(rng.randint(1, _MAX_SIDE)), int(rng.randint(1, max(2, _MAX_SIDE * 3 // 4)))
+        if rng.randint(0, 2):
+            w = (w + 3) // 4 * 4          # rows start on 16-byte boundaries
+        scheme = T.SCHEMES[names[rng.randint(len(names))]]
+        if rng.randint(0, 2):
+            img = rng.rand(h, w, 3).astype(np.float32)
+        else:
+            img = (_content(rng, w, h).astype(np.float32) / np.float32(255.0)) * np.float32(rng.rand())
+        qt = T.quality_tables(int(rng.randint(1, 101))) if rng.randint(0, 2) else rng.randint(1, 256, (3, 64)).astype(np.float32)
+        want = O.encode(img, scheme, qt).jpeg
+        got = ctx.encode_host(img, B.make_params(w, h, scheme, qt))
+        assert got == want, (seed, w, h)
