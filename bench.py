@@ -79,6 +79,27 @@ def cpu_baseline(width, height, scheme, qt, kind):
                       % (w, h, runs, threads)}
 
 
+def stage_rooflines(lay, images, out_bytes, kern_ms):
+    """Achieved GB/s and fraction of the HBM peak per stage and for the three stages together.
+    Bytes a stage has to move: transform 3 B/pixel in + 2 B/coefficient out; histogram
+    2 B/coefficient in; entropy 2 B/coefficient in + the stream written, read and written
+    again stuffed (3 x the output size)."""
+    coef = 128 * int(lay.total_blocks) * images
+    need = {"transform": algorithmic_bytes(lay) * images, "histogram": coef, "entropy": coef + 3 * out_bytes}
+    ms = {"transform": float(kern_ms[0]), "histogram": float(kern_ms[1]), "entropy": float(kern_ms[2])}
+    res = {}
+    for k in need:
+        if ms[k] > 0:
+            gbs = need[k] / (ms[k] * 1e-3) / 1e9
+            res[k] = {"bytes": int(need[k]), "ms": round(ms[k], 4), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBPS, 4)}
+    total_ms = sum(ms[k] for k in res)
+    if total_ms > 0:
+        gbs = sum(need[k] for k in res) / (total_ms * 1e-3) / 1e9
+        res["all"] = {"bytes": int(sum(need[k] for k in res)), "ms": round(total_ms, 4), "achieved": round(gbs, 1),
+                      "frac": round(gbs / HBM_PEAK_GBPS, 4)}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +240,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": measured_traffic(args.workload, world),
                          "algorithmic_bytes_per_launch": int(alg), "kernel_ms": round(float(kern_ms[0]), 4)},
+            # Every stage against the same HBM peak (bytes each stage has to move / its time); the
+            # histogram and bit-writer passes are bound by instruction issue, not by memory.
+            "roofline_stages": stage_rooflines(lay, max(batch, 1), int(n_out), kern_ms),
             "stage_ms": {"transform": round(float(kern_ms[0]), 4), "histogram": round(float(kern_ms[1]), 4),
                          "entropy": round(float(kern_ms[2]), 4), "host_tables": round(float(kern_ms[3]), 4)},
         }

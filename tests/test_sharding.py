@@ -157,3 +157,56 @@ def test_ranks_sharing_one_gpu_match_oracle(world):
     import io
     dec = np.array(Image.open(io.BytesIO(got)).convert("RGB"))
     assert dec.shape == img.shape
+
+
+@pytest.mark.gpu
+def test_full_size_bands_equal_whole_image_and_round_trip():
+    """The 16384 x 16384 4:2:0 q=90 benchmark image, far beyond what the CPU checker encodes in
+    seconds, through properties that do not depend on the size: the pieces of eight bands put
+    together are byte for byte the file of one whole-image call with the same restart interval;
+    that file decodes to exactly the coefficients the encoder held; the decoded pixels are close
+    to the source."""
+    from jpegenc_amd import synth_torch
+    w = h = 16384
+    world = 8
+    scheme, qt = T.SCHEMES["420"], T.quality_tables(90)
+    rgb = synth_torch.generate("natural", w, h, device="cuda")
+    ctxs = [B.Context(0) for _ in range(world)]
+    encs = [sharding.HipBandEncoder(ctxs[r], B, w, h, scheme, qt, world, r) for r in range(world)]
+    hists = [torch.zeros((4, 256), dtype=torch.int64, device="cuda") for _ in range(world)]
+    torch.cuda.synchronize()
+    for r, enc in enumerate(encs):
+        y0, y1 = enc.pixel_rows
+        enc.analyze(rgb[y0:y1].data_ptr(), B.RGB8, w * 3, hists[r].data_ptr())
+    for c in ctxs:
+        torch.cuda.ExternalStream(c.stream).synchronize()
+    total = torch.stack(hists).sum(0).contiguous()      # what the all-reduce leaves on every rank
+    torch.cuda.synchronize()
+    out = torch.zeros(96 << 20, dtype=torch.uint8, device="cuda")
+    pieces = []
+    for enc in encs:
+        n = enc.finish(total.data_ptr(), out.data_ptr(), out.numel())
+        pieces.append(out[:n].clone())
+    sharded = torch.cat(pieces)
+    for c in ctxs[1:]:
+        c.close()
+
+    ctx = ctxs[0]
+    lay0 = B.compute_layout(B.make_params(w, h, scheme, qt))
+    prm = B.make_params(w, h, scheme, qt, restart_interval=lay0.mcus_per_row)
+    lay = B.compute_layout(prm)
+    n = ctx.encode(rgb.data_ptr(), B.RGB8, w * 3, prm, out.data_ptr(), out.numel())
+    assert n == sharded.numel()
+    assert torch.equal(out[:n], sharded)
+    del sharded, pieces
+
+    held = np.concatenate([ctx.coefficients(c, lay).reshape(-1, lay.blocks[c] // (lay.total_blocks // lay.blocks_per_mcu), 64)
+                           for c in range(3)], axis=1).reshape(-1, 64)
+    jpg = out[:n].cpu().numpy().tobytes()
+    dec = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    info = ctx.decode(jpg, dec.data_ptr(), w * 3, dec.numel())
+    assert (info.width, info.height, info.restart_interval) == (w, h, lay0.mcus_per_row)
+    assert np.array_equal(ctx.decoded_coefficients(info), held)
+    mse, psnr = ctx.psnr(rgb.data_ptr(), w * 3, dec.data_ptr(), w * 3, w, h)
+    assert psnr > 33.0, psnr
+    ctx.close()
