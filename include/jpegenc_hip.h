@@ -157,6 +157,14 @@ int jpeg_hip_begin(jpeg_hip_ctx* ctx, const jpeg_hip_params* params);
 /* Image::setRawPixelData / ImageLoader::LoadPNG hand-over (Image.cpp:63-139,
  * ImageLoader.cpp:190-196): copies host pixels into the context's own device buffer. */
 int jpeg_hip_upload_pixels(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format, int64_t stride_bytes);
+/* The same hand-over for a caller that holds the reference's own Image: three planes of
+ * floats in 0..1 (ImageData's r, g, b, Image.h:30-61, filled by Image::setRawPixelData /
+ * transposeFloat, Image.cpp:63-139), rows row_stride_bytes apart (the reference's simulated
+ * width times 4).  Only the image's own width x height samples are read -- the replicated
+ * border the reference keeps around them is rebuilt by the kernels.  The planes are
+ * interleaved on the device; the context then holds float pixels. */
+int jpeg_hip_upload_planes(jpeg_hip_ctx* ctx, const float* h_r, const float* h_g, const float* h_b,
+                           int64_t row_stride_bytes);
 /* Zero-copy variant: uses caller-owned device pixels, which must stay valid until the
  * transform has run. */
 int jpeg_hip_bind_pixels(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes);

@@ -732,25 +732,21 @@ int jpeg_hip_bind_pixels(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format
     return JPEG_HIP_OK;
 }
 
-int jpeg_hip_upload_pixels(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format, int64_t stride_bytes) {
-    if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
-    if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
-    const int st = check_pixels(ctx, h_rgb, sample_format, stride_bytes);
-    if (st != JPEG_HIP_OK) return st;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int rows = std::min(band_rows_available(ctx->geo), ctx->geo.bandRows * ctx->geo.stepH);
-    const size_t rowBytes = (size_t)ctx->geo.width * 3 * bytes_per_sample(sample_format);
-    const size_t dstStride = (rowBytes + 3) / 4 * 4;
-    HIP_TRY(ctx, ctx->pixels.ensure(dstStride * rows));
-    // A two-dimensional copy out of pageable memory goes row by row, ten microseconds each
-    // (1080 rows: 10 ms).  Instead the rows are packed into pinned blocks of about 32 MiB by
-    // a few host threads and sent as one piece each, two blocks taking turns.
+// Rows of rowBytes bytes, stride_bytes apart in host memory, to d_dst with rows dstStride apart.
+// A two-dimensional copy out of pageable memory goes row by row, ten microseconds each
+// (1080 rows: 10 ms).  Instead the rows are packed into pinned blocks of about 32 MiB by
+// a few host threads and sent as one piece each, two blocks taking turns.  Returns with
+// the copies queued on the stream; the caller waits.
+static int upload_rows(jpeg_hip_ctx* ctx, const void* h_src, int64_t stride_bytes, size_t rowBytes, size_t dstStride,
+                       int rows, uint8_t* d_dst) {
     const int rowsPerPiece = (int)std::max<size_t>(1, std::min<size_t>((size_t)rows, (32u << 20) / dstStride));
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(ctx, ctx->uploadStage[i].ensure((size_t)rowsPerPiece * dstStride));
         if (!ctx->uploadEvent[i]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->uploadEvent[i], hipEventDisableTiming));
     }
     if (!ctx->packers) ctx->packers = new WorkerPool(3);
+    // The blocks may still be on their way for an earlier call's rows.
+    for (int i = 0; i < 2; ++i) HIP_TRY(ctx, hipEventSynchronize(ctx->uploadEvent[i]));
     int piece = 0;
     for (int row0 = 0; row0 < rows; row0 += rowsPerPiece, ++piece) {
         const int n = std::min(rowsPerPiece, rows - row0);
@@ -759,7 +755,7 @@ int jpeg_hip_upload_pixels(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_form
         const int slices = n >= 64 ? 16 : 1;
         ctx->packers->run(slices, [&](int t) {
             const int a = n * t / slices, b = n * (t + 1) / slices;
-            const uint8_t* src = (const uint8_t*)h_rgb + (int64_t)(row0 + a) * stride_bytes;
+            const uint8_t* src = (const uint8_t*)h_src + (int64_t)(row0 + a) * stride_bytes;
             uint8_t* dst = stage + (size_t)a * dstStride;
             if ((size_t)stride_bytes == dstStride) {
                 // the source's last row may end with its pixels, not with a full stride
@@ -768,14 +764,60 @@ int jpeg_hip_upload_pixels(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_form
                 for (int y = a; y < b; ++y, src += stride_bytes, dst += dstStride) memcpy(dst, src, rowBytes);
             }
         });
-        HIP_TRY(ctx, hipMemcpyAsync((uint8_t*)ctx->pixels.p + (size_t)row0 * dstStride, stage, (size_t)(n - 1) * dstStride + rowBytes,
+        HIP_TRY(ctx, hipMemcpyAsync(d_dst + (size_t)row0 * dstStride, stage, (size_t)(n - 1) * dstStride + rowBytes,
                                     hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipEventRecord(ctx->uploadEvent[piece & 1], ctx->stream));
     }
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_upload_pixels(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format, int64_t stride_bytes) {
+    if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
+    int st = check_pixels(ctx, h_rgb, sample_format, stride_bytes);
+    if (st != JPEG_HIP_OK) return st;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rows = std::min(band_rows_available(ctx->geo), ctx->geo.bandRows * ctx->geo.stepH);
+    const size_t rowBytes = (size_t)ctx->geo.width * 3 * bytes_per_sample(sample_format);
+    const size_t dstStride = (rowBytes + 3) / 4 * 4;
+    HIP_TRY(ctx, ctx->pixels.ensure(dstStride * rows));
+    st = upload_rows(ctx, h_rgb, stride_bytes, rowBytes, dstStride, rows, (uint8_t*)ctx->pixels.p);
+    if (st != JPEG_HIP_OK) return st;
     HIP_TRY(ctx, wait_stream(ctx));
     ctx->rgb = ctx->pixels.p;
     ctx->fmt = sample_format;
     ctx->stride = (int64_t)dstStride;
+    ctx->hasPixels = true;
+    ctx->transformed = false;
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_upload_planes(jpeg_hip_ctx* ctx, const float* h_r, const float* h_g, const float* h_b, int64_t row_stride_bytes) {
+    if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
+    if (!h_r || !h_g || !h_b) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "plane pointer is null");
+    const size_t rowBytes = (size_t)ctx->geo.width * sizeof(float);
+    if (row_stride_bytes < (int64_t)rowBytes) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "row stride is smaller than one row of samples");
+    if (row_stride_bytes % 4 != 0 || (((uintptr_t)h_r | (uintptr_t)h_g | (uintptr_t)h_b) & 3) != 0)
+        return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "float planes must be 4-byte aligned");
+    if (ctx->prm.standard_huffman)
+        return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "the standard Huffman tables cover 8-bit pixels only");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rows = std::min(band_rows_available(ctx->geo), ctx->geo.bandRows * ctx->geo.stepH);
+    const size_t planeBytes = rowBytes * rows;
+    HIP_TRY(ctx, ctx->pixels.ensure(3 * planeBytes));
+    HIP_TRY(ctx, ctx->pixelsF.ensure(3 * planeBytes));
+    const float* planes[3] = {h_r, h_g, h_b};
+    for (int c = 0; c < 3; ++c) {
+        const int st = upload_rows(ctx, planes[c], row_stride_bytes, rowBytes, rowBytes, rows, (uint8_t*)ctx->pixels.p + c * planeBytes);
+        if (st != JPEG_HIP_OK) return st;
+    }
+    HIP_TRY(ctx, launch_interleave_planes((const float*)ctx->pixels.p, (long long)(planeBytes / sizeof(float)),
+                                          (float*)ctx->pixelsF.p, (long long)rows * ctx->geo.width, ctx->stream));
+    HIP_TRY(ctx, wait_stream(ctx));
+    ctx->rgb = ctx->pixelsF.p;
+    ctx->fmt = JPEG_HIP_RGBF32;
+    ctx->stride = (int64_t)ctx->geo.width * 3 * sizeof(float);
     ctx->hasPixels = true;
     ctx->transformed = false;
     return JPEG_HIP_OK;

@@ -94,6 +94,10 @@ hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qt
 hipError_t launch_pixel_filter(const void* d_src, int sampleFormat, long long srcStride, float* d_dst, int width, int rows,
                                int filter, int channel, float value, hipStream_t s);
 
+// Three packed float planes, planeFloats apart, to interleaved float pixels.
+hipError_t launch_interleave_planes(const float* d_planes, long long planeFloats, float* d_dst, long long pixels,
+                                    hipStream_t s);
+
 // Symbol histograms (uint64[4][256] per image of the batch); d_hist is cleared first unless
 // the caller has done that (launch_clear_histograms) for several launches at once.
 // ex (single images only): the kernel also writes the finished histograms to ex->host, pinned

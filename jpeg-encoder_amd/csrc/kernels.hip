@@ -617,6 +617,25 @@ __global__ __launch_bounds__(256) void k_pixel_filter(const void* __restrict__ s
     p[2] = o[2];
 }
 
+// Three float planes (the reference's ImageData, Image.h:30-61) -> interleaved float pixels.
+// One thread per pixel; the planes lie planeFloats apart, rows packed.
+__global__ __launch_bounds__(256) void k_interleave_planes(const float* __restrict__ planes, long long planeFloats,
+                                                           float* __restrict__ dst, long long pixels) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pixels) return;
+    float* p = dst + i * 3;
+    p[0] = planes[i];
+    p[1] = planes[planeFloats + i];
+    p[2] = planes[2 * planeFloats + i];
+}
+
+hipError_t launch_interleave_planes(const float* d_planes, long long planeFloats, float* d_dst, long long pixels,
+                                    hipStream_t s) {
+    hipLaunchKernelGGL(k_interleave_planes, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, s, d_planes, planeFloats,
+                       d_dst, pixels);
+    return hipGetLastError();
+}
+
 hipError_t launch_pixel_filter(const void* d_src, int sampleFormat, long long srcStride, float* d_dst, int width, int rows,
                                int filter, int channel, float value, hipStream_t s) {
     hipLaunchKernelGGL(k_pixel_filter, dim3((unsigned)((width + 255) / 256), (unsigned)rows), dim3(256), 0, s, d_src,

@@ -20,7 +20,7 @@ DC, AC = 0, 1
 
 EXPORTS = [
     "jpeg_hip_create", "jpeg_hip_destroy", "jpeg_hip_last_error", "jpeg_hip_status_string", "jpeg_hip_stream",
-    "jpeg_hip_compute_layout", "jpeg_hip_encode", "jpeg_hip_encode_host", "jpeg_hip_encode_batch", "jpeg_hip_encode_batch_host", "jpeg_hip_begin", "jpeg_hip_upload_pixels",
+    "jpeg_hip_compute_layout", "jpeg_hip_encode", "jpeg_hip_encode_host", "jpeg_hip_encode_batch", "jpeg_hip_encode_batch_host", "jpeg_hip_begin", "jpeg_hip_upload_pixels", "jpeg_hip_upload_planes",
     "jpeg_hip_bind_pixels", "jpeg_hip_transform", "jpeg_hip_histograms", "jpeg_hip_histograms_host",
     "jpeg_hip_huffman_from_histogram", "jpeg_hip_standard_huffman", "jpeg_hip_write_dht", "jpeg_hip_write_headers", "jpeg_hip_set_huffman",
     "jpeg_hip_build_huffman", "jpeg_hip_get_huffman", "jpeg_hip_emit_scan", "jpeg_hip_emit_scan_host",
@@ -95,6 +95,7 @@ def lib():
         L.jpeg_hip_decoded_coefficients.argtypes = [vp, vp, i64]
         L.jpeg_hip_psnr.argtypes = [vp, vp, i64, vp, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.jpeg_hip_upload_pixels.argtypes = [vp, vp, i32, i64]
+        L.jpeg_hip_upload_planes.argtypes = [vp, vp, vp, vp, i64]
         L.jpeg_hip_bind_pixels.argtypes = [vp, vp, i32, i64]
         L.jpeg_hip_transform.argtypes = [vp, i32]
         L.jpeg_hip_filter_pixels.argtypes = [vp, i32, i32, C.c_float]
@@ -285,6 +286,18 @@ class Context:
         if stride is None:
             stride = rgb.strides[0]
         self._check(lib().jpeg_hip_upload_pixels(self._h, _np(rgb), fmt, stride))
+
+    def upload_planes(self, r, g, b, stride=None):
+        """Three float32 planes (rows ``stride`` bytes apart) instead of interleaved pixels."""
+        planes = [np.asarray(p) for p in (r, g, b)]
+        for p in planes:
+            if p.dtype != np.float32 or p.ndim != 2 or p.strides[1] != 4:
+                raise ValueError("planes are 2-D float32 arrays with packed rows")
+        if stride is None:
+            stride = planes[0].strides[0]
+        if any(p.strides[0] != stride for p in planes):
+            raise ValueError("the planes must share one row stride")
+        self._check(lib().jpeg_hip_upload_planes(self._h, *[C.c_void_p(p.ctypes.data) for p in planes], stride))
 
     def bind_pixels(self, d_rgb, fmt, stride):
         self._check(lib().jpeg_hip_bind_pixels(self._h, C.c_void_p(d_rgb), fmt, stride))

@@ -68,6 +68,30 @@ def test_float_pixels(ctx):
         assert ctx.encode_host(img, prm) == enc.jpeg
 
 
+def test_float_planes_like_the_reference_image(ctx):
+    # Three planes with the reference's layout: padded to whole MCUs ("simulated" size), the
+    # border filled with anything -- only the image's own samples may be read.
+    import torch
+    rng = np.random.RandomState(11)
+    d_out = torch.zeros(1 << 23, dtype=torch.uint8, device="cuda")
+    for (w, h, scheme) in ((70, 45, "420"), (64, 48, "444"), (333, 17, "422"), (1930, 1085, "420")):
+        img = rng.rand(h, w, 3).astype(np.float32)
+        enc = O.encode(img, T.SCHEMES[scheme], T.quality_tables(75))
+        sw, sh = T.padded_size(w, h, T.SCHEMES[scheme])
+        planes = rng.rand(3, sh, sw).astype(np.float32)
+        planes[:, :h, :w] = img.transpose(2, 0, 1)
+        prm = B.make_params(w, h, T.SCHEMES[scheme], T.quality_tables(75))
+        ctx.begin(prm)
+        ctx.upload_planes(planes[0], planes[1], planes[2])
+        ctx.transform()
+        ctx.build_huffman(ctx.histograms())
+        n = ctx.emit_scan(d_out.data_ptr(), d_out.numel())
+        assert d_out[:n].cpu().numpy().tobytes() == enc.scan, (w, h, scheme)
+    with pytest.raises(B.JpegHipError):
+        ctx.begin(B.make_params(8, 8, T.SCHEME_444, T.STANDARD_TABLES, standard_huffman=True))
+        ctx.upload_planes(planes[0], planes[1], planes[2])
+
+
 def test_all_byte_values_and_saturated_blocks(ctx):
     # every byte value in every channel, plus flat black / white / checkerboard extremes
     ramp = np.arange(256, dtype=np.uint8)
