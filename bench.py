@@ -176,6 +176,8 @@ def main():
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
     torch.cuda.synchronize()
 
+    host_reduce = world > 1 and dist.get_backend() != "nccl"
+
     def step():
         if batch:
             lens = ctx.encode_batch(rgb.data_ptr(), B.RGB8, stride, image_stride, batch, params, out.data_ptr(), cap)
@@ -186,7 +188,12 @@ def main():
         if world > 1 and not args.standard_huffman:
             cur = torch.cuda.current_stream()
             cur.wait_stream(ext)
-            dist.all_reduce(hist)
+            if host_reduce:      # gloo rehearsal: through host memory, like tests/test_sharding.py
+                h = hist.cpu()
+                dist.all_reduce(h)
+                hist.copy_(h)
+            else:
+                dist.all_reduce(hist)
             ext.wait_stream(cur)
         # One rank: the band's own histograms are the image's, no summed copy to hand back.
         return ctx.finish_band(hist.data_ptr() if world > 1 else None, out.data_ptr(), cap)
