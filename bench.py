@@ -111,6 +111,8 @@ def main():
                     help="Annex K tables instead of per-image optimised ones: no histogram pass, no host step")
     ap.add_argument("--band-of", type=int, default=0,
                     help="diagnostic: encode only rank 0's band of an image sharded over this many ranks")
+    ap.add_argument("--pipeline-depth", type=int, default=2,
+                    help="images in flight per rank when the image is sharded over several ranks (1: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--analyze-only", action="store_true",
                     help="diagnostic: stop after the transform and the histogram pass (no file is written)")
@@ -203,14 +205,62 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        n_out = step()
+    # Several ranks: a band is a fraction of a millisecond of kernels between two waits of
+    # the host (the all-reduce, the result), so consecutive images are pipelined over
+    # `depth` contexts -- the transform and the histogram pass of image i + 1 run while
+    # image i is reduced and written.  Every image is still encoded completely, in order.
+    depth = max(1, args.pipeline_depth) if (sharded and (world > 1 or args.band_of) and not args.analyze_only) else 1
+    lanes = [(ctx, hist, ext)]
+    for _ in range(depth - 1):
+        c = B.Context(local_rank)
+        c.set_profiling(True)
+        lanes.append((c, torch.zeros((4, 256), dtype=torch.int64, device=dev), torch.cuda.ExternalStream(c.stream, device=dev)))
+    torch.cuda.synchronize()
+
+    def analyze(k):
+        c, h, _ = lanes[k]
+        c.analyze_band(rgb.data_ptr(), B.RGB8, stride, params, h.data_ptr())
+
+    def finish(k):
+        c, h, e = lanes[k]
+        if world > 1 and not args.standard_huffman:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(e)
+            if host_reduce:
+                hh = h.cpu()
+                dist.all_reduce(hh)
+                h.copy_(hh)
+            else:
+                dist.all_reduce(h)
+            e.wait_stream(cur)
+        return c.finish_band(h.data_ptr(), out.data_ptr(), cap)
+
+    def run(count, acc):
+        n, pending = 0, []
+        for i in range(count):
+            if depth == 1:
+                n = step()
+                if acc is not None:
+                    acc += ctx.timings()
+                continue
+            analyze(i % depth)
+            pending.append(i % depth)
+            if len(pending) == depth:
+                k = pending.pop(0)
+                n = finish(k)
+                if acc is not None:
+                    acc += lanes[k][0].timings()
+        for k in pending:
+            n = finish(k)
+            if acc is not None:
+                acc += lanes[k][0].timings()
+        return n
+
+    n_out = run(args.warmup, None)
     sync()
     kern_ms = np.zeros(4)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_out = step()
-        kern_ms += ctx.timings()
+    n_out = run(args.steps, kern_ms)
     sync()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -241,6 +291,7 @@ def main():
                        "huffman": "standard (Annex K)" if args.standard_huffman else "optimised per image",
                        "frames_per_gpu_per_step": batch or None,
                        "parallelism": ("frames-per-gpu x%d" if batch else "band-per-gpu x%d") % world,
+                       "images_in_flight": depth,
                        "jpeg_bytes_rank0": int(n_out)},
             "roofline": {"bound": "hbm", "kernel": "fused transform (colour, subsample, DCT, quantize, zig-zag)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -258,7 +309,8 @@ def main():
         elif not args.no_cpu_baseline:
             res["cpu_baseline"] = None
         print(json.dumps(res))
-    ctx.close()
+    for c, _, _ in lanes:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 
