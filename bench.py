@@ -111,8 +111,8 @@ def main():
                     help="Annex K tables instead of per-image optimised ones: no histogram pass, no host step")
     ap.add_argument("--band-of", type=int, default=0,
                     help="diagnostic: encode only rank 0's band of an image sharded over this many ranks")
-    ap.add_argument("--pipeline-depth", type=int, default=2,
-                    help="images in flight per rank when the image is sharded over several ranks (1: none)")
+    ap.add_argument("--pipeline-depth", type=int, default=3,
+                    help="images in flight per rank when the image is sharded over several ranks (1 to 3; 1: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--analyze-only", action="store_true",
                     help="diagnostic: stop after the transform and the histogram pass (no file is written)")
@@ -205,24 +205,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Several ranks: a band is a fraction of a millisecond of kernels between two waits of
-    # the host (the all-reduce, the result), so consecutive images are pipelined over
-    # `depth` contexts -- the transform and the histogram pass of image i + 1 run while
-    # image i is reduced and written.  Every image is still encoded completely, in order.
-    depth = max(1, args.pipeline_depth) if (sharded and (world > 1 or args.band_of) and not args.analyze_only) else 1
-    lanes = [(ctx, hist, ext)]
+    # Several ranks: a band is a fraction of a millisecond of kernels between waits of the
+    # host (the all-reduce, the histograms, the result), so consecutive images are pipelined
+    # over `depth` contexts.  Depth 3 (the default): while image i is transformed and counted,
+    # image i - 1 is reduced and its bit writer launched, and the result of image i - 2 is
+    # collected.  Depth 2: image i + 1 is transformed while image i is reduced and written.
+    # Every image is still encoded completely and in order, and every rank issues its
+    # all-reduces in the same order.
+    depth = min(3, max(1, args.pipeline_depth)) if (sharded and (world > 1 or args.band_of) and not args.analyze_only) else 1
+    lanes = [(ctx, hist, ext, out)]
     for _ in range(depth - 1):
         c = B.Context(local_rank)
         c.set_profiling(True)
-        lanes.append((c, torch.zeros((4, 256), dtype=torch.int64, device=dev), torch.cuda.ExternalStream(c.stream, device=dev)))
+        lanes.append((c, torch.zeros((4, 256), dtype=torch.int64, device=dev), torch.cuda.ExternalStream(c.stream, device=dev),
+                      torch.empty(cap, dtype=torch.uint8, device=dev)))
     torch.cuda.synchronize()
 
     def analyze(k):
-        c, h, _ = lanes[k]
+        c, h, _, _ = lanes[k]
         c.analyze_band(rgb.data_ptr(), B.RGB8, stride, params, h.data_ptr())
 
-    def finish(k):
-        c, h, e = lanes[k]
+    def reduce(k):
+        _, h, e, _ = lanes[k]
         if world > 1 and not args.standard_huffman:
             cur = torch.cuda.current_stream()
             cur.wait_stream(e)
@@ -233,27 +237,41 @@ def main():
             else:
                 dist.all_reduce(h)
             e.wait_stream(cur)
-        return c.finish_band(h.data_ptr(), out.data_ptr(), cap)
+
+    def start(k):
+        reduce(k)
+        c, h, _, o = lanes[k]
+        c.finish_band_start(h.data_ptr(), o.data_ptr(), cap)
+
+    def wait(k, acc):
+        n = lanes[k][0].finish_band_wait()
+        if acc is not None:
+            acc += lanes[k][0].timings()
+        return n
 
     def run(count, acc):
-        n, pending = 0, []
-        for i in range(count):
-            if depth == 1:
+        n = 0
+        if depth == 1:
+            for _ in range(count):
                 n = step()
                 if acc is not None:
                     acc += ctx.timings()
-                continue
-            analyze(i % depth)
-            pending.append(i % depth)
-            if len(pending) == depth:
-                k = pending.pop(0)
-                n = finish(k)
-                if acc is not None:
-                    acc += lanes[k][0].timings()
-        for k in pending:
-            n = finish(k)
-            if acc is not None:
-                acc += lanes[k][0].timings()
+            return n
+        if depth == 2:
+            for i in range(count + 1):
+                if i < count:
+                    analyze(i % 2)
+                if i >= 1:
+                    start((i - 1) % 2)
+                    n = wait((i - 1) % 2, acc)
+            return n
+        for i in range(count + 2):
+            if i < count:
+                analyze(i % 3)
+            if 1 <= i <= count:
+                start((i - 1) % 3)
+            if i >= 2:
+                n = wait((i - 2) % 3, acc)
         return n
 
     n_out = run(args.warmup, None)
@@ -309,8 +327,8 @@ def main():
         elif not args.no_cpu_baseline:
             res["cpu_baseline"] = None
         print(json.dumps(res))
-    for c, _, _ in lanes:
-        c.close()
+    for lane in lanes:
+        lane[0].close()
     if world > 1:
         dist.destroy_process_group()
 

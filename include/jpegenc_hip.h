@@ -268,6 +268,16 @@ int jpeg_hip_analyze_band(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_forma
 int jpeg_hip_finish_band(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t* d_out, int64_t out_capacity,
                          int64_t* out_len);
 
+/* jpeg_hip_finish_band in two halves, for a caller that keeps several images in flight on
+ * several contexts (a band of a sharded image is a fraction of a millisecond of kernels;
+ * a host that sits out every wait leaves the GPU idle most of the time): _start builds the
+ * tables and launches the kernels that write the piece, _wait returns when they are done
+ * and gives the length.  Between the two the context accepts no other call that starts
+ * new work (jpeg_hip_begin and the one-call entry points return JPEG_HIP_ERR_BAD_STATE).
+ * The reference, which encodes one image at a time on the host, has no counterpart. */
+int jpeg_hip_finish_band_start(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t* d_out, int64_t out_capacity);
+int jpeg_hip_finish_band_wait(jpeg_hip_ctx* ctx, int64_t* out_len);
+
 /* Timing of the last jpeg_hip_encode / analyze / finish in milliseconds, measured with HIP
  * events on the context's stream: [0] fused transform kernel, [1] histogram kernel,
  * [2] entropy kernels (clears, bit writer, stuffing), [3] host table build.

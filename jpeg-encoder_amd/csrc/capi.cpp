@@ -235,6 +235,7 @@ struct jpeg_hip_ctx {
     Geometry geo;
     KGeom kg;
     bool begun = false, hasPixels = false, transformed = false, hasTables = false, qtabOnDevice = false;
+    bool scanInFlight = false;                   // between jpeg_hip_finish_band_start and _wait
     int64_t stagedScanLen = -1;   // scan of the current coefficients and tables held in `staging`, or -1
     int64_t streamBits = -1;      // entropy-coded bits the installed tables spend on the histograms they came from, or -1
     const void* rgb = nullptr;
@@ -477,7 +478,8 @@ int build_tables(jpeg_hip_ctx* ctx, const uint64_t* hist, bool stageHeader = fal
 
 // Runs the entropy kernels and reads the length back.  prefix: bytes already placed at
 // the start of d_out (headers).
-int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capacity, int writeEoi, int64_t* outLen) {
+// Launches the entropy kernels; run_entropy_wait collects their result.
+int run_entropy_launch(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capacity, int writeEoi) {
     mark(ctx, 3);
     ctx->kg.writeEoi = writeEoi;
     // The histograms (and so streamBits) cover the whole image even when this context encodes a band.
@@ -502,6 +504,10 @@ int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capac
     HIP_TRY(ctx, launch_entropy(ctx->kg, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, d_out,
                                 prefix, capacity, writeEoi, ctx->stream));
     mark(ctx, 4);
+    return JPEG_HIP_OK;
+}
+
+int run_entropy_wait(jpeg_hip_ctx* ctx, int64_t* outLen) {
     HIP_TRY(ctx, wait_stream(ctx));
     if (ctx->profiling) {
         float ms = 0;
@@ -513,6 +519,11 @@ int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capac
     if (ctx->pin->result[1] != 0) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "output buffer is too small for the scan");
     *outLen = (int64_t)ctx->pin->result[0];
     return JPEG_HIP_OK;
+}
+
+int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capacity, int writeEoi, int64_t* outLen) {
+    const int st = run_entropy_launch(ctx, d_out, prefix, capacity, writeEoi);
+    return st != JPEG_HIP_OK ? st : run_entropy_wait(ctx, outLen);
 }
 
 // staged: the call comes from jpeg_hip_transform, which honours jpeg_hip_channel_gain.
@@ -690,6 +701,7 @@ int jpeg_hip_compute_layout(const jpeg_hip_params* params, jpeg_hip_layout* out)
 
 int jpeg_hip_begin(jpeg_hip_ctx* ctx, const jpeg_hip_params* params) {
     if (!ctx || !params) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Geometry g;
     const int st = make_geometry(*params, g);
@@ -721,6 +733,7 @@ int jpeg_hip_begin(jpeg_hip_ctx* ctx, const jpeg_hip_params* params) {
 
 int jpeg_hip_bind_pixels(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes) {
     if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
     const int st = check_pixels(ctx, d_rgb, sample_format, stride_bytes);
     if (st != JPEG_HIP_OK) return st;
@@ -773,6 +786,7 @@ static int upload_rows(jpeg_hip_ctx* ctx, const void* h_src, int64_t stride_byte
 
 int jpeg_hip_upload_pixels(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format, int64_t stride_bytes) {
     if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
     int st = check_pixels(ctx, h_rgb, sample_format, stride_bytes);
     if (st != JPEG_HIP_OK) return st;
@@ -794,6 +808,7 @@ int jpeg_hip_upload_pixels(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_form
 
 int jpeg_hip_upload_planes(jpeg_hip_ctx* ctx, const float* h_r, const float* h_g, const float* h_b, int64_t row_stride_bytes) {
     if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
     if (!h_r || !h_g || !h_b) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "plane pointer is null");
     const size_t rowBytes = (size_t)ctx->geo.width * sizeof(float);
@@ -830,6 +845,7 @@ static int band_pixel_rows(const jpeg_hip_ctx* ctx) {
 
 int jpeg_hip_filter_pixels(jpeg_hip_ctx* ctx, int filter, int channel, float value) {
     if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     if (!ctx->begun || !ctx->hasPixels) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "filters need begin() and pixels");
     if ((filter != JPEG_HIP_FILTER_SEPIA && filter != JPEG_HIP_FILTER_MULTIPLY) || channel < 0 || channel > 2)
         return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "unknown filter or channel");
@@ -881,18 +897,21 @@ int jpeg_hip_get_pixels(jpeg_hip_ctx* ctx, float* h_rgb, int64_t capacity_floats
 
 int jpeg_hip_transform(jpeg_hip_ctx* ctx, int stages) {
     if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return do_transform(ctx, stages, true);
 }
 
 int jpeg_hip_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist) {
     if (!ctx || !d_hist) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return do_histograms(ctx, d_hist);
 }
 
 int jpeg_hip_histograms_host(jpeg_hip_ctx* ctx, uint64_t* h_hist) {
     if (!ctx || !h_hist) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int st = do_histograms(ctx, (uint64_t*)ctx->hist.p);
     if (st != JPEG_HIP_OK) return st;
@@ -931,6 +950,7 @@ int jpeg_hip_write_headers(const jpeg_hip_params* params, const uint8_t lengths[
 
 int jpeg_hip_set_huffman(jpeg_hip_ctx* ctx, const uint8_t lengths[4][256], const uint16_t codes[4][256]) {
     if (!ctx || !lengths || !codes) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     memcpy(ctx->lengths, lengths, sizeof ctx->lengths);
@@ -940,6 +960,7 @@ int jpeg_hip_set_huffman(jpeg_hip_ctx* ctx, const uint8_t lengths[4][256], const
 
 int jpeg_hip_build_huffman(jpeg_hip_ctx* ctx, const uint64_t h_hist[4][256]) {
     if (!ctx || !h_hist) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return build_tables(ctx, &h_hist[0][0]);
@@ -955,6 +976,7 @@ int jpeg_hip_get_huffman(jpeg_hip_ctx* ctx, uint8_t lengths[4][256], uint16_t co
 
 int jpeg_hip_emit_scan(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t out_capacity, int64_t* out_len) {
     if (!ctx || !d_out || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     if (!ctx->transformed || !ctx->hasTables) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "emit needs coefficients and tables");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return run_entropy(ctx, d_out, 0, out_capacity, 0, out_len);
@@ -962,6 +984,7 @@ int jpeg_hip_emit_scan(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t out_capacity, 
 
 int jpeg_hip_emit_scan_host(jpeg_hip_ctx* ctx, uint8_t* h_out, int64_t out_capacity, int64_t* out_len) {
     if (!ctx || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     if (!ctx->transformed || !ctx->hasTables) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "emit needs coefficients and tables");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->stagedScanLen < 0) {
@@ -1027,12 +1050,31 @@ int jpeg_hip_analyze_band(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_forma
 int jpeg_hip_finish_band(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t* d_out, int64_t out_capacity,
                          int64_t* out_len) {
     if (!ctx || !d_out || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    const int st = jpeg_hip_finish_band_start(ctx, d_hist_sum, d_out, out_capacity);
+    if (st != JPEG_HIP_OK) return st;
+    return jpeg_hip_finish_band_wait(ctx, out_len);
+}
+
+int jpeg_hip_finish_band_start(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t* d_out, int64_t out_capacity) {
+    if (!ctx || !d_out) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (!ctx->transformed) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "finish needs analyze");
+    if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int headerLen = 0;
-    const int st = fetch_hist_and_build(ctx, d_hist_sum, out_capacity, &headerLen);
+    int st = fetch_hist_and_build(ctx, d_hist_sum, out_capacity, &headerLen);
     if (st != JPEG_HIP_OK) return st;
-    return run_entropy(ctx, d_out, headerLen, out_capacity, ctx->geo.endsImage ? 1 : 0, out_len);
+    st = run_entropy_launch(ctx, d_out, headerLen, out_capacity, ctx->geo.endsImage ? 1 : 0);
+    if (st != JPEG_HIP_OK) return st;
+    ctx->scanInFlight = true;
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_finish_band_wait(jpeg_hip_ctx* ctx, int64_t* out_len) {
+    if (!ctx || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if (!ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "no jpeg_hip_finish_band_start to wait for");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->scanInFlight = false;
+    return run_entropy_wait(ctx, out_len);
 }
 
 int jpeg_hip_encode(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,

@@ -25,7 +25,7 @@ EXPORTS = [
     "jpeg_hip_huffman_from_histogram", "jpeg_hip_standard_huffman", "jpeg_hip_write_dht", "jpeg_hip_write_headers", "jpeg_hip_set_huffman",
     "jpeg_hip_build_huffman", "jpeg_hip_get_huffman", "jpeg_hip_emit_scan", "jpeg_hip_emit_scan_host",
     "jpeg_hip_get_coefficients",
-    "jpeg_hip_coefficients_device", "jpeg_hip_analyze_band", "jpeg_hip_finish_band", "jpeg_hip_set_profiling",
+    "jpeg_hip_coefficients_device", "jpeg_hip_analyze_band", "jpeg_hip_finish_band", "jpeg_hip_finish_band_start", "jpeg_hip_finish_band_wait", "jpeg_hip_set_profiling",
     "jpeg_hip_get_timings", "jpeg_hip_decode_info", "jpeg_hip_decode", "jpeg_hip_decode_host",
     "jpeg_hip_decoded_coefficients", "jpeg_hip_psnr", "jpeg_hip_filter_pixels", "jpeg_hip_get_pixels", "jpeg_hip_channel_gain",
 ]
@@ -117,6 +117,8 @@ def lib():
         L.jpeg_hip_coefficients_device.restype = vp
         L.jpeg_hip_analyze_band.argtypes = [vp, vp, i32, i64, C.POINTER(Params), vp]
         L.jpeg_hip_finish_band.argtypes = [vp, vp, vp, i64, C.POINTER(i64)]
+        L.jpeg_hip_finish_band_start.argtypes = [vp, vp, vp, i64]
+        L.jpeg_hip_finish_band_wait.argtypes = [vp, C.POINTER(i64)]
         L.jpeg_hip_set_profiling.argtypes = [vp, i32]
         L.jpeg_hip_get_timings.argtypes = [vp, vp]
         _lib = L
@@ -356,6 +358,15 @@ class Context:
         # d_hist_sum None: the band is the whole image, use the histograms as analyze_band counted them
         self._check(lib().jpeg_hip_finish_band(self._h, C.c_void_p(d_hist_sum) if d_hist_sum else None, C.c_void_p(d_out), capacity,
                                                C.byref(n)))
+        return n.value
+
+    def finish_band_start(self, d_hist_sum, d_out, capacity):
+        self._check(lib().jpeg_hip_finish_band_start(self._h, C.c_void_p(d_hist_sum) if d_hist_sum else None,
+                                                     C.c_void_p(d_out), capacity))
+
+    def finish_band_wait(self):
+        n = C.c_int64(0)
+        self._check(lib().jpeg_hip_finish_band_wait(self._h, C.byref(n)))
         return n.value
 
     def set_profiling(self, enabled):

@@ -237,3 +237,41 @@ def test_staged_table_sequences(ctx):
     assert ctx.encode_host(b, prm) == eb.jpeg
     assert emit() == eb.scan
     assert ctx.emit_scan_host() == eb.scan
+
+
+def test_finish_band_in_two_halves_and_images_in_flight(ctx):
+    """jpeg_hip_finish_band_start / _wait: the same bytes as the one-call form, with three
+    images in flight on three contexts, and the calls that must wait their turn refused."""
+    import torch
+    qt = T.quality_tables(85)
+    imgs = [synth.generate("natural", 640, 360, seed=s) for s in (5, 6, 7, 8, 9)]
+    prm = B.make_params(640, 360, T.SCHEME_420, qt)
+    want = [ctx.encode_host(im, prm) for im in imgs]
+    lanes = [B.Context(0) for _ in range(3)]
+    d_imgs = [torch.from_numpy(im).cuda() for im in imgs]
+    outs = [torch.zeros(1 << 20, dtype=torch.uint8, device="cuda") for _ in lanes]
+    torch.cuda.synchronize()
+    got = [None] * len(imgs)
+    for i in range(len(imgs) + 2):
+        if i < len(imgs):
+            lanes[i % 3].analyze_band(d_imgs[i].data_ptr(), B.RGB8, 640 * 3, prm, None)
+        if 1 <= i <= len(imgs):
+            lanes[(i - 1) % 3].finish_band_start(None, outs[(i - 1) % 3].data_ptr(), outs[0].numel())
+        if i >= 2:
+            k = (i - 2) % 3
+            n = lanes[k].finish_band_wait()
+            got[i - 2] = outs[k][:n].cpu().numpy().tobytes()
+    assert got == want
+    c = lanes[0]
+    c.analyze_band(d_imgs[0].data_ptr(), B.RGB8, 640 * 3, prm, None)
+    c.finish_band_start(None, outs[0].data_ptr(), outs[0].numel())
+    for refused in (lambda: c.begin(prm), lambda: c.finish_band_start(None, outs[0].data_ptr(), outs[0].numel()),
+                    lambda: c.encode_host(imgs[0], prm), lambda: c.transform()):
+        with pytest.raises(B.JpegHipError):
+            refused()
+    n = c.finish_band_wait()
+    assert outs[0][:n].cpu().numpy().tobytes() == want[0]
+    with pytest.raises(B.JpegHipError):
+        c.finish_band_wait()
+    for c in lanes:
+        c.close()
