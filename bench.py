@@ -111,8 +111,10 @@ def main():
                     help="Annex K tables instead of per-image optimised ones: no histogram pass, no host step")
     ap.add_argument("--band-of", type=int, default=0,
                     help="diagnostic: encode only rank 0's band of an image sharded over this many ranks")
-    ap.add_argument("--pipeline-depth", type=int, default=3,
-                    help="images in flight per rank when the image is sharded over several ranks (1 to 3; 1: none)")
+    ap.add_argument("--pipeline-depth", type=int, default=1,
+                    help="images in flight per rank in the timed region, 1 to 3 (sharded workloads)")
+    ap.add_argument("--pipelined-steps", type=int, default=50,
+                    help="steps of the extra measurement with three images in flight, reported as \"pipelined\" (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--analyze-only", action="store_true",
                     help="diagnostic: stop after the transform and the histogram pass (no file is written)")
@@ -205,21 +207,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Several ranks: a band is a fraction of a millisecond of kernels between waits of the
-    # host (the all-reduce, the histograms, the result), so consecutive images are pipelined
-    # over `depth` contexts.  Depth 3 (the default): while image i is transformed and counted,
-    # image i - 1 is reduced and its bit writer launched, and the result of image i - 2 is
-    # collected.  Depth 2: image i + 1 is transformed while image i is reduced and written.
-    # Every image is still encoded completely and in order, and every rank issues its
-    # all-reduces in the same order.
-    depth = min(3, max(1, args.pipeline_depth)) if (sharded and (world > 1 or args.band_of) and not args.analyze_only) else 1
+    # A band of an image sharded over several ranks is a fraction of a millisecond of kernels
+    # between waits of the host (the all-reduce, the histograms, the result).  The timed region
+    # encodes one image at a time (depth 1), which is what one large image costs.  A stream of
+    # images can be pipelined over `depth` contexts.  Depth 3: while image i is transformed and
+    # counted, image i - 1 is reduced and its bit writer launched, and the result of image
+    # i - 2 is collected.  Depth 2: image i + 1 is transformed while image i is reduced and
+    # written.  Every image is still encoded completely and in order, and every rank issues
+    # its all-reduces in the same order.
+    depth = min(3, max(1, args.pipeline_depth)) if (sharded and not args.analyze_only) else 1
     lanes = [(ctx, hist, ext, out)]
-    for _ in range(depth - 1):
-        c = B.Context(local_rank)
-        c.set_profiling(True)
-        lanes.append((c, torch.zeros((4, 256), dtype=torch.int64, device=dev), torch.cuda.ExternalStream(c.stream, device=dev),
-                      torch.empty(cap, dtype=torch.uint8, device=dev)))
-    torch.cuda.synchronize()
+
+    def add_lanes(total):
+        while len(lanes) < total:
+            c = B.Context(local_rank)
+            c.set_profiling(True)
+            lanes.append((c, torch.zeros((4, 256), dtype=torch.int64, device=dev),
+                          torch.cuda.ExternalStream(c.stream, device=dev), torch.empty(cap, dtype=torch.uint8, device=dev)))
+        torch.cuda.synchronize()
+
+    add_lanes(depth)
 
     def analyze(k):
         c, h, _, _ = lanes[k]
@@ -241,7 +248,7 @@ def main():
     def start(k):
         reduce(k)
         c, h, _, o = lanes[k]
-        c.finish_band_start(h.data_ptr(), o.data_ptr(), cap)
+        c.finish_band_start(h.data_ptr() if world > 1 else None, o.data_ptr(), cap)
 
     def wait(k, acc):
         n = lanes[k][0].finish_band_wait()
@@ -249,7 +256,7 @@ def main():
             acc += lanes[k][0].timings()
         return n
 
-    def run(count, acc):
+    def run(count, acc, depth=depth):
         n = 0
         if depth == 1:
             for _ in range(count):
@@ -287,6 +294,25 @@ def main():
     elapsed = float(tmax.item())
     kern_ms /= max(args.steps, 1)
 
+    # For information beside the headline: the same images three in flight per rank (see
+    # above).  Kernels of neighbouring images then share the GPU, so their individual
+    # durations say nothing about the kernels; the roofline figures stay those of the timed
+    # region above, where one image is in flight.
+    in_flight = None
+    if depth == 1 and sharded and not args.analyze_only and not args.band_of and args.pipelined_steps > 0:
+        add_lanes(3)
+        run(min(args.warmup, 5), None, 3)
+        sync()
+        t1 = time.perf_counter()
+        run(args.pipelined_steps, None, 3)
+        sync()
+        tp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        dt = float(tp.item()) / args.pipelined_steps
+        in_flight = {"images_in_flight": 3, "steps": args.pipelined_steps, "ms_per_step": round(dt * 1e3, 4),
+                     "value": round(width * height / 1e6 / dt, 1), "unit": "MP/s"}
+
     if rank == 0:
         mp = width * height / 1e6 * (batch * world if batch else 1)
         ms_per_step = elapsed / args.steps * 1e3
@@ -322,6 +348,8 @@ def main():
             "stage_ms": {"transform": round(float(kern_ms[0]), 4), "histogram": round(float(kern_ms[1]), 4),
                          "entropy": round(float(kern_ms[2]), 4), "host_tables": round(float(kern_ms[3]), 4)},
         }
+        if in_flight is not None:
+            res["pipelined"] = in_flight
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(width, height, scheme, qt, kind)
         elif not args.no_cpu_baseline:
