@@ -2,7 +2,7 @@
 set -e
 WL=${1:-16k_420_q90}; TAG=${2:-prof}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --workload $WL > gpurun_out/$TAG.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --pipelined-steps 0 --workload $WL > gpurun_out/$TAG.log 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob('gpurun_out/$TAG/*/*kernel_stats.csv')[0]
