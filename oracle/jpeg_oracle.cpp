@@ -18,6 +18,7 @@
 // round-half-to-even.  Extensions that the reference does not have (restart
 // intervals, selectable pad bit) are marked "extension".
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -397,6 +398,34 @@ float normalise(Sample s);
 template <> float normalise<u8>(u8 s) { return s / 255.0f; }      // ImageLoader.cpp:190-193
 template <> float normalise<float>(float s) { return s; }        // Image::setRawPixelData takes floats
 
+// A channel plane without the zero fill of std::vector (a serial pass over 4 bytes per
+// sample that also takes the page faults away from the parallel loops).
+struct Plane {
+    float* p = nullptr;
+    Plane() = default;
+    Plane(const Plane&) = delete;
+    Plane& operator=(const Plane&) = delete;
+    ~Plane() { free(p); }
+    void resize(size_t n) {
+        p = (float*)malloc(n * sizeof(float));
+        if (!p) abort();
+    }
+    float& operator[](size_t i) { return p[i]; }
+    float* data() { return p; }
+};
+
+// ORC_TIMING=1 in the environment prints the seconds spent per stage to stderr.
+struct StageClock {
+    bool on = getenv("ORC_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "  %-28s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
+        t = n;
+    }
+};
+
 template <typename Sample>
 void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Scheme& sc, const float qt[3][64],
                  int restartInterval, bool padOnes, const uint64_t* histOverride, int rstBase, int headerH,
@@ -406,7 +435,8 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
     const int simH = H + (H % sc.stepH == 0 ? 0 : sc.stepH - H % sc.stepH);
     res.simW = simW; res.simH = simH;
     const size_t plane = (size_t)simW * simH;
-    std::vector<float> ch[3];
+    StageClock clk;
+    Plane ch[3];   // every sample is written by the de-interleave below
     for (int c = 0; c < 3; ++c) ch[c].resize(plane);
 
     // Image::setRawPixelData, Image.cpp:63-139: de-interleave; pixels outside the real
@@ -424,6 +454,7 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
         }
     }
 
+    clk.lap("planes");
     // Encoder::convertToYCbCr, Encoder.cpp:15-23.
 #pragma omp parallel for
     for (int64_t i = 0; i < (int64_t)plane; ++i) {
@@ -436,6 +467,7 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
         if (op.stage == 0)
             for (size_t i = 0; i < plane; ++i) ch[op.channel][i] *= op.value;
 
+    clk.lap("colour");
     // Encoder::reduceResolutionBySchema, Encoder.cpp:157-166: all width passes, then all
     // height passes, in place and compacting.
     int cw[3] = {simW, simW, simW}, chh[3] = {simH, simH, simH};
@@ -465,8 +497,14 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
         const int64_t n = w * chh[c];
         chh[c] /= f;
         if (sc.hm[c] == 1 && f == 2) {      // halfHeightResolutionAverageAVX, SIMD256.h:295-304
-            for (int64_t x = 0; x < w; ++x)
-                for (int64_t s = x, d = x; s < n; s += w * 2, d += w) p[d] = (p[s] + p[s + w]) / 2.0f;
+            // Row by row (the vector order of the reference's kernel); every output depends on
+            // its own two inputs only, and output row r is written after rows 2r and 2r + 1 are read.
+            for (int64_t r = 0; r < n / (w * 2); ++r) {
+                float* d = p + r * w;
+                const float* a = p + 2 * r * w;
+                const float* b = a + w;
+                for (int64_t x = 0; x < w; ++x) d[x] = (a[x] + b[x]) / 2.0f;
+            }
         } else if (sc.hm[c] == 0) {
             for (int64_t s = 0; s < n; s += w * f) memmove(p + s / f, p + s, (size_t)w * sizeof(float));
         } else {                            // Encoder.cpp:137-154
@@ -485,6 +523,7 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
         if (op.stage == 1)
             for (int64_t i = 0; i < (int64_t)cw[op.channel] * chh[op.channel]; ++i) ch[op.channel][i] *= op.value;
 
+    clk.lap("reduce");
     // Encoder::applyDCT per channel, Encoder.cpp:229-258.
     std::vector<BlockSymbols> sym[3];
     const int mcusPerRow = simW / sc.stepW;
@@ -546,6 +585,7 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
         }
     }
 
+    clk.lap("dct + symbols");
     // Encoder::createHuffmanTable, Encoder.cpp:368-416: four tables, chroma shared.
     memset(res.hist, 0, sizeof res.hist);
     for (int c = 0; c < 3; ++c) {
@@ -571,6 +611,7 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
         }
     }
 
+    clk.lap("histograms + tables");
     // Encoder::serialize, Encoder.cpp:439-488.
     BitSink sink;
     std::vector<u8> hdr;
@@ -644,6 +685,7 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
     const u8 eoi[2] = {0xff, 0xd9};
     sink.pushBytes(eoi, 2);
     res.jpeg.assign(sink.data.begin(), sink.data.begin() + sink.byteLen());
+    clk.lap("bit stream");
 }
 
 }  // namespace
