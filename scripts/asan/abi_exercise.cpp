@@ -115,6 +115,41 @@ int main() {
             CHECK(jpeg_hip_finish_band(ctx, nullptr, dOut, 1 << 22, &len));
             CHECK(jpeg_hip_encode(ctx, dRgb, JPEG_HIP_RGB8, w * 3, &p, dOut, 1 << 22, &len));
         }
+        // the two halves of finish_band, two contexts taking turns; a refused call in between
+        {
+            jpeg_hip_ctx* other = nullptr;
+            CHECK(jpeg_hip_create(0, &other));
+            uint8_t* dOut2 = nullptr;
+            if (hipMalloc(&dOut2, 1 << 22) != hipSuccess) return 3;
+            int64_t la = 0, lb = 0;
+            for (int rep = 0; rep < 3; ++rep) {
+                CHECK(jpeg_hip_analyze_band(ctx, dRgb, JPEG_HIP_RGB8, w * 3, &p, nullptr));
+                CHECK(jpeg_hip_analyze_band(other, dRgb, JPEG_HIP_RGB8, w * 3, &p, nullptr));
+                CHECK(jpeg_hip_finish_band_start(ctx, nullptr, dOut, 1 << 22));
+                CHECK(jpeg_hip_finish_band_start(other, nullptr, dOut2, 1 << 22));
+                if (jpeg_hip_begin(ctx, &p) != JPEG_HIP_ERR_BAD_STATE) return 4;
+                CHECK(jpeg_hip_finish_band_wait(ctx, &la));
+                CHECK(jpeg_hip_finish_band_wait(other, &lb));
+                if (la != lb || la != len) return 4;
+            }
+            (void)hipFree(dOut2);
+            jpeg_hip_destroy(other);
+        }
+        // three float planes with padded rows (the reference Image's layout), odd width
+        {
+            const int pw = 333, ph = 77, sw = 336, sh = 80;
+            std::vector<float> planes((size_t)3 * sw * sh);
+            for (size_t i = 0; i < planes.size(); ++i) planes[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65535.0f;
+            jpeg_hip_params pp = make_params(pw, ph, true);
+            CHECK(jpeg_hip_begin(ctx, &pp));
+            CHECK(jpeg_hip_upload_planes(ctx, planes.data(), planes.data() + (size_t)sw * sh, planes.data() + (size_t)2 * sw * sh,
+                                         (int64_t)sw * sizeof(float)));
+            CHECK(jpeg_hip_transform(ctx, JPEG_HIP_STAGE_ALL));
+            CHECK(jpeg_hip_histograms_host(ctx, &hist[0][0]));
+            CHECK(jpeg_hip_build_huffman(ctx, hist));
+            int64_t n2 = 0;
+            CHECK(jpeg_hip_emit_scan_host(ctx, nullptr, 0, &n2));
+        }
         // device batch, small
         const int n = 40;
         uint8_t* dFrames = nullptr;
