@@ -215,7 +215,7 @@ def main():
     # i - 2 is collected.  Depth 2: image i + 1 is transformed while image i is reduced and
     # written.  Every image is still encoded completely and in order, and every rank issues
     # its all-reduces in the same order.
-    depth = min(3, max(1, args.pipeline_depth)) if (sharded and not args.analyze_only) else 1
+    depth = min(3, max(1, args.pipeline_depth)) if (not batch and not args.analyze_only) else 1
     lanes = [(ctx, hist, ext, out)]
 
     def add_lanes(total):
@@ -299,7 +299,7 @@ def main():
     # durations say nothing about the kernels; the roofline figures stay those of the timed
     # region above, where one image is in flight.
     in_flight = None
-    if depth == 1 and sharded and not args.analyze_only and not args.band_of and args.pipelined_steps > 0:
+    if depth == 1 and not batch and not args.analyze_only and not args.band_of and args.pipelined_steps > 0:
         add_lanes(3)
         run(min(args.warmup, 5), None, 3)
         sync()
