@@ -15,6 +15,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -294,25 +295,6 @@ def main():
     elapsed = float(tmax.item())
     kern_ms /= max(args.steps, 1)
 
-    # For information beside the headline: the same images three in flight per rank (see
-    # above).  Kernels of neighbouring images then share the GPU, so their individual
-    # durations say nothing about the kernels; the roofline figures stay those of the timed
-    # region above, where one image is in flight.
-    in_flight = None
-    if depth == 1 and not batch and not args.analyze_only and not args.band_of and args.pipelined_steps > 0:
-        add_lanes(3)
-        run(min(args.warmup, 5), None, 3)
-        sync()
-        t1 = time.perf_counter()
-        run(args.pipelined_steps, None, 3)
-        sync()
-        tp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-        dt = float(tp.item()) / args.pipelined_steps
-        in_flight = {"images_in_flight": 3, "steps": args.pipelined_steps, "ms_per_step": round(dt * 1e3, 4),
-                     "value": round(width * height / 1e6 / dt, 1), "unit": "MP/s"}
-
     if rank == 0:
         mp = width * height / 1e6 * (batch * world if batch else 1)
         ms_per_step = elapsed / args.steps * 1e3
@@ -348,13 +330,50 @@ def main():
             "stage_ms": {"transform": round(float(kern_ms[0]), 4), "histogram": round(float(kern_ms[1]), 4),
                          "entropy": round(float(kern_ms[2]), 4), "host_tables": round(float(kern_ms[3]), 4)},
         }
-        if in_flight is not None:
-            res["pipelined"] = in_flight
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(width, height, scheme, qt, kind)
         elif not args.no_cpu_baseline:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
+
+    # The extra measurement below must never cost the line above: if it has not come back
+    # after two minutes (it never took more than a second), every rank leaves and rank 0
+    # prints what it has.
+    def give_up():
+        if rank == 0:
+            res["pipelined"] = {"error": "no result within 120 s"}
+            print(json.dumps(res), flush=True)
+        os._exit(0)
+
+    watchdog = threading.Timer(120.0, give_up)
+    watchdog.daemon = True
+    watchdog.start()
+    # For information beside the headline: the same images three in flight per rank (see
+    # above).  Kernels of neighbouring images then share the GPU, so their individual
+    # durations say nothing about the kernels; the roofline figures stay those of the timed
+    # region above, where one image is in flight.
+    in_flight = None
+    try:
+        if depth == 1 and not batch and not args.analyze_only and not args.band_of and args.pipelined_steps > 0:
+            add_lanes(3)
+            run(min(args.warmup, 5), None, 3)
+            sync()
+            t1 = time.perf_counter()
+            run(args.pipelined_steps, None, 3)
+            sync()
+            tp = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            dt = float(tp.item()) / args.pipelined_steps
+            in_flight = {"images_in_flight": 3, "steps": args.pipelined_steps, "ms_per_step": round(dt * 1e3, 4),
+                         "value": round(width * height / 1e6 / dt, 1), "unit": "MP/s"}
+    except Exception as e:      # reported, not fatal: the headline stands on its own
+        in_flight = {"error": "%s: %s" % (type(e).__name__, e)}
+    watchdog.cancel()
+
+    if rank == 0:
+        if in_flight is not None:
+            res["pipelined"] = in_flight
+        print(json.dumps(res), flush=True)
     for lane in lanes:
         lane[0].close()
     if world > 1:
