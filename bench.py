@@ -282,6 +282,10 @@ def main():
                 n = wait((i - 2) % 3, acc)
         return n
 
+    # One step before the warm-up proper: workspaces are allocated and, with several ranks, the
+    # communicator is set up by the first collective -- neither belongs to a timed step even
+    # when the caller asks for no warm-up.
+    n_out = run(1, None)
     n_out = run(args.warmup, None)
     sync()
     kern_ms = np.zeros(4)
