@@ -241,6 +241,7 @@ struct jpeg_hip_ctx {
     const void* rgb = nullptr;
     int fmt = JPEG_HIP_RGB8;
     int64_t stride = 0;
+    DevBuf repacked;                             // byte pixels whose rows did not start on 4-byte boundaries, rows realigned
     DevBuf pixels, coef, qtab, hist, tables, ivOff, ffCount, groupSum, result, unstuffed,
         staging, batchHdr, batchHdrLen, batchFfStart, tileState, decCoef, decPlanes, decTables, decRgb, decSum, pixelsF, pipeIn[2], pipeOut;
     jpeghip::DecodedStream* decoded = nullptr;   // last file given to the verification decoder
@@ -545,8 +546,21 @@ int do_transform(jpeg_hip_ctx* ctx, int stages, bool staged = false, uint64_t* c
             ctx->kg.gains[i].value = ctx->gains[i].value;
         }
     }
+    // The fast kernels read byte pixels in dwords.  Caller-owned rows that do not start on
+    // 4-byte boundaries (an odd width, packed) are realigned by a copy kernel first, a
+    // fraction of what the byte-wise kernel would cost.
+    const void* rgb = ctx->rgb;
+    if (ctx->fmt == JPEG_HIP_RGB8 && stages == JPEG_HIP_STAGE_ALL && ctx->kg.nGains == 0 &&
+        ((ctx->stride & 3) != 0 || ((uintptr_t)rgb & 3) != 0)) {
+        const int rows = std::min(band_rows_available(g), g.bandRows * g.stepH);
+        const size_t rowBytes = (size_t)g.width * 3, dstStride = (rowBytes + 15) / 16 * 16;
+        HIP_TRY(ctx, ctx->repacked.ensure(dstStride * rows));
+        HIP_TRY(ctx, launch_realign_rows(rgb, ctx->stride, ctx->repacked.p, (long long)dstStride, (int)rowBytes, rows, ctx->stream));
+        rgb = ctx->repacked.p;
+        ctx->kg.strideBytes = (long long)dstStride;
+    }
     mark(ctx, 0);
-    HIP_TRY(ctx, launch_transform(ctx->kg, ctx->rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, ctx->stream,
+    HIP_TRY(ctx, launch_transform(ctx->kg, rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, ctx->stream,
                                   (unsigned long long*)clearHist));
     mark(ctx, 1);
     ctx->transformed = true;
@@ -641,7 +655,7 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->groupSum, &ctx->result,
                       &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart,
                       &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum, &ctx->pixelsF, &ctx->pipeIn[0], &ctx->pipeIn[1],
-                      &ctx->pipeOut, &ctx->histDone, &ctx->gather};
+                      &ctx->pipeOut, &ctx->histDone, &ctx->gather, &ctx->repacked};
     delete ctx->decoded;
     delete ctx->workers;
     delete ctx->packers;

@@ -617,6 +617,37 @@ __global__ __launch_bounds__(256) void k_pixel_filter(const void* __restrict__ s
     p[2] = o[2];
 }
 
+// Rows of bytes that start anywhere -> rows that start on 16-byte boundaries.  A thread makes
+// 16 bytes of a row from the five aligned dwords that hold them (v_alignbyte); dwords past
+// the last source byte are not touched.  Bytes of a destination row behind rowBytes are padding.
+__global__ __launch_bounds__(256) void k_realign_rows(const unsigned char* __restrict__ src, long long srcStride,
+                                                      unsigned char* __restrict__ dst, long long dstStride, int rowBytes,
+                                                      int rows) {
+    const int unit = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (16 * unit >= rowBytes) return;
+    const unsigned char* s = src + (long long)y * srcStride + 16 * (long long)unit;
+    const unsigned char* end = src + (long long)(rows - 1) * srcStride + rowBytes;
+    const int shift = (int)((uintptr_t)s & 3);
+    const u32* a = (const u32*)(s - shift);
+    u32 w[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) w[i] = (const unsigned char*)(a + i) < end ? a[i] : 0u;
+    uint4 o;
+    o.x = __builtin_amdgcn_alignbyte(w[1], w[0], shift);
+    o.y = __builtin_amdgcn_alignbyte(w[2], w[1], shift);
+    o.z = __builtin_amdgcn_alignbyte(w[3], w[2], shift);
+    o.w = __builtin_amdgcn_alignbyte(w[4], w[3], shift);
+    *(uint4*)(dst + (long long)y * dstStride + 16 * (long long)unit) = o;
+}
+
+hipError_t launch_realign_rows(const void* d_src, long long srcStride, void* d_dst, long long dstStride, int rowBytes,
+                               int rows, hipStream_t s) {
+    const int units = (rowBytes + 15) / 16;
+    hipLaunchKernelGGL(k_realign_rows, dim3((unsigned)((units + 255) / 256), (unsigned)rows), dim3(256), 0, s,
+                       (const unsigned char*)d_src, srcStride, (unsigned char*)d_dst, dstStride, rowBytes, rows);
+    return hipGetLastError();
+}
+
 // Three float planes (the reference's ImageData, Image.h:30-61) -> interleaved float pixels.
 // One thread per pixel; the planes lie planeFloats apart, rows packed.
 __global__ __launch_bounds__(256) void k_interleave_planes(const float* __restrict__ planes, long long planeFloats,

@@ -275,3 +275,23 @@ def test_finish_band_in_two_halves_and_images_in_flight(ctx):
         c.finish_band_wait()
     for c in lanes:
         c.close()
+
+
+def test_device_rows_off_dword_boundaries(ctx):
+    """Caller-owned byte pixels with an odd row stride and an odd first address."""
+    import torch
+    rng = np.random.RandomState(21)
+    d_out = torch.zeros(1 << 22, dtype=torch.uint8, device="cuda")
+    for (w, h, scheme, pad, off) in ((1001, 333, "420", 0, 0), (1366, 200, "444", 1, 3), (77, 50, "422", 2, 1), (640, 91, "420", 3, 2)):
+        img = synth.generate("natural", w, h, seed=w)
+        stride = w * 3 + pad
+        buf = rng.randint(0, 256, off + stride * h + 8).astype(np.uint8)
+        view = buf[off:off + stride * h].reshape(h, stride)
+        view[:, :w * 3] = img.reshape(h, w * 3)
+        d_buf = torch.from_numpy(buf).cuda()
+        torch.cuda.synchronize()
+        qt = T.quality_tables(80)
+        want = O.encode(img, T.SCHEMES[scheme], qt).jpeg
+        prm = B.make_params(w, h, T.SCHEMES[scheme], qt)
+        n = ctx.encode(d_buf.data_ptr() + off, B.RGB8, stride, prm, d_out.data_ptr(), d_out.numel())
+        assert d_out[:n].cpu().numpy().tobytes() == want, (w, h, scheme, pad, off)
