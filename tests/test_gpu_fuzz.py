@@ -111,3 +111,28 @@ def test_random_configurations_float_pixels(ctx, seed):
         want = O.encode(img, scheme, qt).jpeg
         got = ctx.encode_host(img, B.make_params(w, h, scheme, qt))
         assert got == want, (seed, w, h)
+
+
+@pytest.mark.parametrize("seed", range(max(4, _SEEDS // 4)))
+def test_random_device_buffers(ctx, seed):
+    # Caller-owned device pixels: any row stride, any first address.
+    import torch
+    rng = np.random.RandomState(9000 + seed)
+    names = sorted(T.SCHEMES)
+    d_out = torch.zeros(8 << 20, dtype=torch.uint8, device="cuda")
+    for _ in range(6):
+        w, h = int(rng.randint(1, _MAX_SIDE)), int(rng.randint(1, max(2, _MAX_SIDE * 3 // 4)))
+        scheme = T.SCHEMES[names[rng.randint(len(names))]]
+        img = _content(rng, w, h)
+        pad, off = int(rng.randint(0, 9)), int(rng.randint(0, 8))
+        stride = w * 3 + pad
+        buf = rng.randint(0, 256, off + stride * h + 16).astype(np.uint8)
+        buf[off:off + stride * h].reshape(h, stride)[:, :w * 3] = img.reshape(h, w * 3)
+        d_buf = torch.from_numpy(buf).cuda()
+        torch.cuda.synchronize()
+        qt = T.quality_tables(int(rng.randint(1, 101)))
+        ri = 0 if rng.randint(0, 2) else int(rng.randint(1, 50))
+        want = O.encode(img, scheme, qt, restart_interval=ri).jpeg
+        prm = B.make_params(w, h, scheme, qt, restart_interval=ri)
+        n = ctx.encode(d_buf.data_ptr() + off, B.RGB8, stride, prm, d_out.data_ptr(), d_out.numel())
+        assert d_out[:n].cpu().numpy().tobytes() == want, (seed, w, h, pad, off)
