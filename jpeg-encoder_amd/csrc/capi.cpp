@@ -527,6 +527,24 @@ int run_entropy(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capac
     return st != JPEG_HIP_OK ? st : run_entropy_wait(ctx, outLen);
 }
 
+// Byte pixels of `images` images (rowsPerImage rows each, imageStride apart) copied into
+// ctx->repacked with rows on 16-byte boundaries and the images packed; *dstStride receives
+// the new row stride.
+int realign_pixels(jpeg_hip_ctx* ctx, const void* src, int64_t stride, int64_t imageStride, int rowsPerImage, int images,
+                   int width, int64_t* dstStride) {
+    const size_t rowBytes = (size_t)width * 3, pitch = (rowBytes + 15) / 16 * 16;
+    HIP_TRY(ctx, ctx->repacked.ensure(pitch * rowsPerImage * images));
+    const int perLaunch = std::max(1, 65535 / rowsPerImage);
+    for (int first = 0; first < images; first += perLaunch) {
+        const int cnt = std::min(perLaunch, images - first);
+        HIP_TRY(ctx, launch_realign_rows((const uint8_t*)src + (int64_t)first * imageStride, stride, imageStride, rowsPerImage,
+                                         (uint8_t*)ctx->repacked.p + (size_t)first * rowsPerImage * pitch, (long long)pitch,
+                                         (int)rowBytes, cnt * rowsPerImage, ctx->stream));
+    }
+    *dstStride = (int64_t)pitch;
+    return JPEG_HIP_OK;
+}
+
 // staged: the call comes from jpeg_hip_transform, which honours jpeg_hip_channel_gain.
 // clearHist: histograms the caller will count into right afterwards (do_histograms with
 // cleared = true).
@@ -553,9 +571,9 @@ int do_transform(jpeg_hip_ctx* ctx, int stages, bool staged = false, uint64_t* c
     if (ctx->fmt == JPEG_HIP_RGB8 && stages == JPEG_HIP_STAGE_ALL && ctx->kg.nGains == 0 &&
         ((ctx->stride & 3) != 0 || ((uintptr_t)rgb & 3) != 0)) {
         const int rows = std::min(band_rows_available(g), g.bandRows * g.stepH);
-        const size_t rowBytes = (size_t)g.width * 3, dstStride = (rowBytes + 15) / 16 * 16;
-        HIP_TRY(ctx, ctx->repacked.ensure(dstStride * rows));
-        HIP_TRY(ctx, launch_realign_rows(rgb, ctx->stride, ctx->repacked.p, (long long)dstStride, (int)rowBytes, rows, ctx->stream));
+        int64_t dstStride = 0;
+        const int st = realign_pixels(ctx, rgb, ctx->stride, 0, rows, 1, g.width, &dstStride);
+        if (st != JPEG_HIP_OK) return st;
         rgb = ctx->repacked.p;
         ctx->kg.strideBytes = (long long)dstStride;
     }
@@ -1186,6 +1204,15 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     k.batch = n;
     k.nMcu = g.nMcu * n;
     k.totalBlocks = g.totalBlocks * n;
+    // Frames whose rows do not start on 4-byte boundaries are realigned first (see do_transform).
+    if (ctx->fmt == JPEG_HIP_RGB8 && ((ctx->stride & 3) != 0 || (imageStride & 3) != 0 || ((uintptr_t)d_rgb & 3) != 0)) {
+        int64_t dstStride = 0;
+        const int st = realign_pixels(ctx, d_rgb, ctx->stride, imageStride, g.height, n, g.width, &dstStride);
+        if (st != JPEG_HIP_OK) return st;
+        d_rgb = (const uint8_t*)ctx->repacked.p;
+        imageStride = dstStride * g.height;
+        k.strideBytes = (long long)dstStride;
+    }
     k.imageStrideBytes = imageStride;
     k.mcusPerInterval = g.nMcu;
     k.intervals = n;

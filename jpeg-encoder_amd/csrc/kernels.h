@@ -95,9 +95,11 @@ hipError_t launch_pixel_filter(const void* d_src, int sampleFormat, long long sr
                                int filter, int channel, float value, hipStream_t s);
 
 // Copies rows of rowBytes bytes from any address and stride to rows dstStride apart
-// (d_dst and dstStride multiples of 16; dstStride >= rowBytes rounded up to 16).
-hipError_t launch_realign_rows(const void* d_src, long long srcStride, void* d_dst, long long dstStride, int rowBytes,
-                               int rows, hipStream_t s);
+// (d_dst and dstStride multiples of 16; dstStride >= rowBytes rounded up to 16).  The
+// source rows are those of images of rowsPerImage rows, srcImageStride apart; at most
+// 65535 rows per launch.
+hipError_t launch_realign_rows(const void* d_src, long long srcStride, long long srcImageStride, int rowsPerImage,
+                               void* d_dst, long long dstStride, int rowBytes, int rows, hipStream_t s);
 
 // Three packed float planes, planeFloats apart, to interleaved float pixels.
 hipError_t launch_interleave_planes(const float* d_planes, long long planeFloats, float* d_dst, long long pixels,

@@ -620,13 +620,16 @@ __global__ __launch_bounds__(256) void k_pixel_filter(const void* __restrict__ s
 // Rows of bytes that start anywhere -> rows that start on 16-byte boundaries.  A thread makes
 // 16 bytes of a row from the five aligned dwords that hold them (v_alignbyte); dwords past
 // the last source byte are not touched.  Bytes of a destination row behind rowBytes are padding.
+// Row y belongs to image y / rowsPerImage (images srcImageStride apart, packed in the copy).
 __global__ __launch_bounds__(256) void k_realign_rows(const unsigned char* __restrict__ src, long long srcStride,
+                                                      long long srcImageStride, int rowsPerImage,
                                                       unsigned char* __restrict__ dst, long long dstStride, int rowBytes,
                                                       int rows) {
     const int unit = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (16 * unit >= rowBytes) return;
-    const unsigned char* s = src + (long long)y * srcStride + 16 * (long long)unit;
-    const unsigned char* end = src + (long long)(rows - 1) * srcStride + rowBytes;
+    const int img = y / rowsPerImage, last = (rows - 1) / rowsPerImage;
+    const unsigned char* s = src + img * srcImageStride + (long long)(y - img * rowsPerImage) * srcStride + 16 * (long long)unit;
+    const unsigned char* end = src + last * srcImageStride + (long long)(rows - 1 - last * rowsPerImage) * srcStride + rowBytes;
     const int shift = (int)((uintptr_t)s & 3);
     const u32* a = (const u32*)(s - shift);
     u32 w[5];
@@ -640,11 +643,12 @@ __global__ __launch_bounds__(256) void k_realign_rows(const unsigned char* __res
     *(uint4*)(dst + (long long)y * dstStride + 16 * (long long)unit) = o;
 }
 
-hipError_t launch_realign_rows(const void* d_src, long long srcStride, void* d_dst, long long dstStride, int rowBytes,
-                               int rows, hipStream_t s) {
+hipError_t launch_realign_rows(const void* d_src, long long srcStride, long long srcImageStride, int rowsPerImage,
+                               void* d_dst, long long dstStride, int rowBytes, int rows, hipStream_t s) {
     const int units = (rowBytes + 15) / 16;
     hipLaunchKernelGGL(k_realign_rows, dim3((unsigned)((units + 255) / 256), (unsigned)rows), dim3(256), 0, s,
-                       (const unsigned char*)d_src, srcStride, (unsigned char*)d_dst, dstStride, rowBytes, rows);
+                       (const unsigned char*)d_src, srcStride, srcImageStride, rowsPerImage, (unsigned char*)d_dst,
+                       dstStride, rowBytes, rows);
     return hipGetLastError();
 }
 
