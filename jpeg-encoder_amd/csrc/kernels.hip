@@ -948,6 +948,14 @@ __device__ __forceinline__ int bit_category(int v) {   // Encoder::lookupBitCate
     return 32 - __clz(a);   // __clz(0) == 32
 }
 
+// Number of leading bits equal to the sign bit (v_ffbh_i32; the compiler has no builtin for
+// it and expands __builtin_clrsb into several instructions).  Not for 0 and -1.
+__device__ __forceinline__ int leading_sign_bits(int x) {
+    int r;
+    asm("v_ffbh_i32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 __device__ __forceinline__ int coef_at(const u32 (&w)[32], int i) {
     return (int)(short)(w[i >> 1] >> ((i & 1) * 16));
 }
@@ -1019,8 +1027,12 @@ __device__ __forceinline__ void walk_block(const u32 (&w)[32], int pred, Visitor
                     vis.zrl(run >> 4);
                     run &= 15;
                 }
-                const int cat = bit_category(v);
-                vis.ac((run << 4) | cat, cat, (u32)(v < 0 ? v - 1 : v) & ((1u << cat) - 1u));
+                // The amplitude bits are those of v, or of v - 1 (the one's complement of |v|)
+                // for a negative v; either way the category is the number of bits left
+                // after the redundant sign bits (never 0 or -1 here: v is not 0).
+                const int amp = v + (v >> 31);
+                const int cat = 32 - leading_sign_bits(amp);
+                vis.ac((run << 4) | cat, cat, (u32)amp & ((1u << cat) - 1u));
             }
         }
     }
