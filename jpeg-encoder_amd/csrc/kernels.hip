@@ -1927,7 +1927,7 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     else
         hipLaunchKernelGGL(k_encode_bits<false>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
                            ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult);
-    long long chunkGrid = chunkBound < 2048 ? chunkBound : 2048;
+    long long chunkGrid = chunkBound < 4096 ? chunkBound : 4096;
     if (chunkGrid < 1) chunkGrid = 1;
     long long countGrid = (chunkBound + 3) / 4;
     countGrid = countGrid < 1 ? 1 : (countGrid > 4096 ? 4096 : countGrid);
