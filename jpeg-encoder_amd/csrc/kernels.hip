@@ -1626,23 +1626,34 @@ __device__ __forceinline__ bool is_marker_ff(const KGeom& g, const u64* __restri
     return ivOff[lo] == i && interval_marker_bytes(g, lo) != 0;
 }
 
+__device__ __forceinline__ u32 ff_bits(u32 w) {   // bit k: byte k of w is 0xFF
+    u32 t = w & (w >> 4);
+    t &= t >> 2;
+    t &= t >> 1;
+    // The flags sit at bits 0, 8, 16, 24; the product brings them to bits 24..27 (no two of
+    // the sixteen partial products meet, so nothing carries).
+    return ((t & 0x01010101u) * 0x01020408u) >> 24;
+}
+
 // Loads 16 stream bytes (plus one of lookahead) and returns a 16-bit mask of the data bytes
 // equal to 0xFF, i.e. those that need a 0x00 behind them (BitBuffer.cpp:156-161, 171-176,
-// 190-195).  Bytes past the end of the stream are zero.
+// 190-195).  Only bytes of the stream count.
 __device__ __forceinline__ u32 stuff_mask(const KGeom& g, const uint8_t* __restrict__ buf,
                                           const u64* __restrict__ ivOff, u64 bytes, long long i0, uint4& q) {
     q = *(const uint4*)(buf + i0);
-    if (count_ff(q.x) + count_ff(q.y) + count_ff(q.z) + count_ff(q.w) == 0) return 0;
-    const u32 ws[5] = {q.x, q.y, q.z, q.w, (u32)buf[i0 + 16]};
-    u32 mask = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint8_t cur = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
-        const uint8_t nxt = (uint8_t)(ws[(j + 1) >> 2] >> (((j + 1) & 3) * 8));
-        if (cur == 0xff && (u64)(i0 + j) < bytes) {
-            const bool maybe = (nxt >= 0xd0 && nxt <= 0xd7) || nxt == 0xd9;
-            if (!(maybe && is_marker_ff(g, ivOff, bytes, (u64)(i0 + j), nxt))) mask |= 1u << j;
-        }
+    u32 ff = ff_bits(q.x) | (ff_bits(q.y) << 4) | (ff_bits(q.z) << 8) | (ff_bits(q.w) << 12);
+    const long long left = (long long)bytes - i0;
+    if (left < 16) ff &= left > 0 ? (1u << (int)left) - 1u : 0u;
+    if (ff == 0) return 0;
+    // One round per 0xFF byte of the piece (one or two as a rule) instead of one per byte.
+    const u64 lo = (u64)q.x | ((u64)q.y << 32), hi = (u64)q.z | ((u64)q.w << 32);
+    const u32 last = (u32)buf[i0 + 16];
+    u32 mask = ff;
+    for (u32 todo = ff; todo != 0; todo &= todo - 1) {
+        const int j = __builtin_ctz(todo), n = j + 1;
+        const uint8_t nxt = (uint8_t)(n < 8 ? lo >> (8 * n) : (n < 16 ? hi >> (8 * (n - 8)) : (u64)last));
+        const bool maybe = (nxt >= 0xd0 && nxt <= 0xd7) || nxt == 0xd9;
+        if (maybe && is_marker_ff(g, ivOff, bytes, (u64)(i0 + j), nxt)) mask &= ~(1u << j);
     }
     return mask;
 }
