@@ -15,9 +15,7 @@
 #include <thread>
 #include <vector>
 
-#include "decode.h"
-#include "internal.h"
-#include "kernels.h"
+#include "context.h"
 
 using namespace jpeghip;
 
@@ -88,197 +86,6 @@ int make_geometry(const jpeg_hip_params& p, Geometry& g) {
 
 namespace {
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        if (p) {
-            hipError_t e = hipFree(p);
-            p = nullptr;
-            cap = 0;
-            if (e != hipSuccess) return e;
-        }
-        // Grow with headroom so a stream of slightly different images does not reallocate.
-        size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {
-            p = nullptr;
-            return e;
-        }
-        cap = want;
-        return hipSuccess;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-// Growable pinned host block.
-struct HostBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        release();
-        const size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-        if (e != hipSuccess) {
-            p = nullptr;
-            return e;
-        }
-        cap = want;
-        return hipSuccess;
-    }
-    void release() {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-constexpr int kHeaderCapacity = 2048;
-
-struct Pinned {
-    float qtab[3 * 192];   // divisors, then the high and low parts of their reciprocals
-    uint64_t hist[4 * 256];
-    uint32_t tables[4 * 256];           // tables and header travel to the device in one copy
-    uint8_t header[kHeaderCapacity];
-    uint64_t result[4];
-};
-
-// Host threads that stay around between batch passes: starting sixteen threads costs more
-// than the table work they are started for.
-class WorkerPool {
-public:
-    explicit WorkerPool(int threads) {
-        for (int i = 0; i < threads; ++i) threads_.emplace_back([this] { loop(); });
-    }
-    ~WorkerPool() {
-        {
-            std::lock_guard<std::mutex> lock(m_);
-            stop_ = true;
-            stopFlag_.store(true);
-        }
-        wake_.notify_all();
-        for (auto& t : threads_) t.join();
-    }
-    int size() const { return (int)threads_.size(); }
-    // Calls fn(i) for every i in [0, n), on the pool's threads and the caller's, and returns
-    // when all calls have returned.  One run at a time.
-    void run(int n, const std::function<void(int)>& fn) {
-        bool asleep;
-        {
-            std::lock_guard<std::mutex> lock(m_);
-            fn_ = &fn;
-            n_ = n;
-            next_.store(0);
-            busy_.store((int)threads_.size());
-            asleep = sleepers_ > 0;
-            generation_.fetch_add(1);
-        }
-        if (asleep) wake_.notify_all();
-        for (int i; (i = next_.fetch_add(1)) < n;) fn(i);
-        while (busy_.load() != 0) std::this_thread::yield();
-        fn_ = nullptr;
-    }
-
-private:
-    void loop() {
-        uint64_t seen = 0;
-        for (;;) {
-            // Runs of one batch pass follow each other within a fraction of a millisecond, and
-            // waking a sleeping thread takes about as long as its share of a run: stay awake
-            // for a while after a run before going to sleep.
-            const auto idleSince = std::chrono::steady_clock::now();
-            while (generation_.load() == seen && !stopFlag_.load() &&
-                   std::chrono::steady_clock::now() - idleSince < std::chrono::microseconds(500))
-                std::this_thread::yield();
-            const std::function<void(int)>* fn;
-            int n;
-            {
-                std::unique_lock<std::mutex> lock(m_);
-                ++sleepers_;
-                wake_.wait(lock, [&] { return stop_ || generation_.load() != seen; });
-                --sleepers_;
-                if (stop_) return;
-                seen = generation_.load();
-                fn = fn_;
-                n = n_;
-            }
-            for (int i; (i = next_.fetch_add(1)) < n;) (*fn)(i);
-            busy_.fetch_sub(1);
-        }
-    }
-    std::vector<std::thread> threads_;
-    std::mutex m_;
-    std::condition_variable wake_;
-    const std::function<void(int)>* fn_ = nullptr;
-    int n_ = 0, sleepers_ = 0;
-    std::atomic<int> next_{0}, busy_{0};
-    std::atomic<uint64_t> generation_{0};
-    std::atomic<bool> stopFlag_{false};
-    bool stop_ = false;
-};
-
-}  // namespace
-
-constexpr int kBatchParts = 8;   // pieces a batch pass is cut into to hide the host's table building
-
-struct jpeg_hip_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string err = "";
-    jpeg_hip_params prm;
-    Geometry geo;
-    KGeom kg;
-    bool begun = false, hasPixels = false, transformed = false, hasTables = false, qtabOnDevice = false;
-    bool scanInFlight = false;                   // between jpeg_hip_finish_band_start and _wait
-    int64_t stagedScanLen = -1;   // scan of the current coefficients and tables held in `staging`, or -1
-    int64_t streamBits = -1;      // entropy-coded bits the installed tables spend on the histograms they came from, or -1
-    const void* rgb = nullptr;
-    int fmt = JPEG_HIP_RGB8;
-    int64_t stride = 0;
-    DevBuf repacked;                             // byte pixels whose rows did not start on 4-byte boundaries, rows realigned
-    DevBuf pixels, coef, qtab, hist, tables, ivOff, ffCount, groupSum, result, unstuffed,
-        staging, batchHdr, batchHdrLen, batchFfStart, tileState, decCoef, decPlanes, decTables, decRgb, decSum, pixelsF, pipeIn[2], pipeOut;
-    jpeghip::DecodedStream* decoded = nullptr;   // last file given to the verification decoder
-    WorkerPool* workers = nullptr;               // created by the first batch pass
-    WorkerPool* packers = nullptr;               // pack host pixels into pinned memory (uploads, jpeg_hip_encode_batch_host)
-    HostBuf uploadStage[2];                      // pinned blocks jpeg_hip_upload_pixels sends its pieces from
-    hipEvent_t uploadEvent[2] = {nullptr, nullptr};
-    DevBuf gather;                               // one channel's coefficients, contiguous (jpeg_hip_get_coefficients)
-    DevBuf histDone;                             // counter of the histogram kernel's host export
-    unsigned long long histExpected = 0;         // value of that counter once every launch so far has finished
-    bool histOnHost = false;                     // pin->hist holds the current band's histograms as counted
-    bool tablesPending = false;                  // pin->tables (+ pendingHeaderLen header bytes) are not on the device yet
-    int pendingHeaderLen = 0;
-    int nGains = 0;                              // jpeg_hip_channel_gain calls since begin()
-    struct {
-        int channel, afterSubsampling;
-        float value;
-    } gains[JPEG_HIP_MAX_GAINS];
-    HostBuf hostHist, hostTables, hostHdr, hostHdrLen, hostOffsets, pipeStage[2];
-    hipStream_t copyStream = nullptr;
-    hipEvent_t pipeEvent[2] = {nullptr, nullptr};
-    hipStream_t histStream = nullptr;            // carries a batch pass's histograms to the host
-    hipStream_t tableStream = nullptr;           // ... and its tables and headers to the device
-    hipEvent_t partCounted[kBatchParts] = {};    // a part of a batch pass has its histograms
-    hipEvent_t partEvent[kBatchParts] = {};      // ... and they are on the host
-    hipEvent_t groupTime[2][3] = {};             // profiling: before a group's transform, behind it, behind its histogram parts
-    EntropyWorkspace ws;
-    Pinned* pin = nullptr;
-    uint8_t lengths[4][256];
-    uint16_t codes[4][256];
-    bool profiling = false;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    float times[4] = {0, 0, 0, 0};
-};
-
-namespace {
-
 int fail(jpeg_hip_ctx* ctx, int status, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return status;
@@ -293,6 +100,27 @@ int hip_fail(jpeg_hip_ctx* ctx, hipError_t e, const char* what) {
         hipError_t e_ = (call);                                 \
         if (e_ != hipSuccess) return hip_fail(ctx, e_, #call);  \
     } while (0)
+
+// Makes the context's GPU the calling thread's current device for the length of an entry
+// point and puts the caller's device back on every way out.
+struct DeviceScope {
+    int previous = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device) {
+        if (hipGetDevice(&previous) != hipSuccess) previous = -1;
+        if (previous != device) err = hipSetDevice(device);
+        else previous = -1;   // nothing to put back
+    }
+    ~DeviceScope() {
+        if (previous >= 0) (void)hipSetDevice(previous);
+    }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
+#define ENTER_DEVICE(ctx)                                                              \
+    DeviceScope deviceScope_((ctx)->device);                                           \
+    if (deviceScope_.err != hipSuccess) return hip_fail(ctx, deviceScope_.err, "hipSetDevice")
 
 int bytes_per_sample(int fmt) { return fmt == JPEG_HIP_RGBF32 ? 4 : 1; }
 
@@ -583,6 +411,9 @@ int do_transform(jpeg_hip_ctx* ctx, int stages, bool staged = false, uint64_t* c
     mark(ctx, 1);
     ctx->transformed = true;
     ctx->stagedScanLen = -1;
+    // Whatever histograms the installed tables came from, they did not count these
+    // coefficients: the bit count derived from them bounds nothing any more.
+    ctx->streamBits = -1;
     return JPEG_HIP_OK;
 }
 
@@ -648,7 +479,8 @@ int jpeg_hip_create(int device_id, jpeg_hip_ctx** out_ctx) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return JPEG_HIP_ERR_NO_DEVICE;
     if (device_id < 0 || device_id >= count) return JPEG_HIP_ERR_INVALID_ARGUMENT;
-    if (hipSetDevice(device_id) != hipSuccess) return JPEG_HIP_ERR_HIP;
+    DeviceScope scope(device_id);
+    if (scope.err != hipSuccess) return JPEG_HIP_ERR_HIP;
     jpeg_hip_ctx* ctx = new (std::nothrow) jpeg_hip_ctx();
     if (!ctx) return JPEG_HIP_ERR_HIP;
     ctx->device = device_id;
@@ -668,7 +500,7 @@ int jpeg_hip_create(int device_id, jpeg_hip_ctx** out_ctx) {
 
 void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceScope scope(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->groupSum, &ctx->result,
                       &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart,
@@ -734,7 +566,7 @@ int jpeg_hip_compute_layout(const jpeg_hip_params* params, jpeg_hip_layout* out)
 int jpeg_hip_begin(jpeg_hip_ctx* ctx, const jpeg_hip_params* params) {
     if (!ctx || !params) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     Geometry g;
     const int st = make_geometry(*params, g);
     if (st != JPEG_HIP_OK) return fail(ctx, st, "invalid image parameters");
@@ -822,7 +654,7 @@ int jpeg_hip_upload_pixels(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_form
     if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
     int st = check_pixels(ctx, h_rgb, sample_format, stride_bytes);
     if (st != JPEG_HIP_OK) return st;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     const int rows = std::min(band_rows_available(ctx->geo), ctx->geo.bandRows * ctx->geo.stepH);
     const size_t rowBytes = (size_t)ctx->geo.width * 3 * bytes_per_sample(sample_format);
     const size_t dstStride = (rowBytes + 3) / 4 * 4;
@@ -849,7 +681,7 @@ int jpeg_hip_upload_planes(jpeg_hip_ctx* ctx, const float* h_r, const float* h_g
         return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "float planes must be 4-byte aligned");
     if (ctx->prm.standard_huffman)
         return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "the standard Huffman tables cover 8-bit pixels only");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     const int rows = std::min(band_rows_available(ctx->geo), ctx->geo.bandRows * ctx->geo.stepH);
     const size_t planeBytes = rowBytes * rows;
     HIP_TRY(ctx, ctx->pixels.ensure(3 * planeBytes));
@@ -883,7 +715,7 @@ int jpeg_hip_filter_pixels(jpeg_hip_ctx* ctx, int filter, int channel, float val
         return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "unknown filter or channel");
     if (ctx->prm.standard_huffman)
         return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "the standard Huffman tables cover 8-bit pixels only");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     const int rows = band_pixel_rows(ctx), width = ctx->geo.width;
     HIP_TRY(ctx, ctx->pixelsF.ensure((size_t)rows * width * 3 * sizeof(float)));
     HIP_TRY(ctx, launch_pixel_filter(ctx->rgb, ctx->fmt, ctx->stride, (float*)ctx->pixelsF.p, width, rows, filter, channel,
@@ -913,7 +745,7 @@ int jpeg_hip_channel_gain(jpeg_hip_ctx* ctx, int channel, float value, int after
 int jpeg_hip_get_pixels(jpeg_hip_ctx* ctx, float* h_rgb, int64_t capacity_floats) {
     if (!ctx || !h_rgb) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (!ctx->begun || !ctx->hasPixels) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "no pixels");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     const int rows = band_pixel_rows(ctx), width = ctx->geo.width;
     const int64_t n = (int64_t)rows * width * 3;
     if (capacity_floats < n) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "pixel buffer too small");
@@ -930,21 +762,21 @@ int jpeg_hip_get_pixels(jpeg_hip_ctx* ctx, float* h_rgb, int64_t capacity_floats
 int jpeg_hip_transform(jpeg_hip_ctx* ctx, int stages) {
     if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     return do_transform(ctx, stages, true);
 }
 
 int jpeg_hip_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist) {
     if (!ctx || !d_hist) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     return do_histograms(ctx, d_hist);
 }
 
 int jpeg_hip_histograms_host(jpeg_hip_ctx* ctx, uint64_t* h_hist) {
     if (!ctx || !h_hist) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     const int st = do_histograms(ctx, (uint64_t*)ctx->hist.p);
     if (st != JPEG_HIP_OK) return st;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pin->hist, ctx->hist.p, sizeof ctx->pin->hist, hipMemcpyDeviceToHost, ctx->stream));
@@ -984,7 +816,10 @@ int jpeg_hip_set_huffman(jpeg_hip_ctx* ctx, const uint8_t lengths[4][256], const
     if (!ctx || !lengths || !codes) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int t = 0; t < 4; ++t)
+        if (!huffman_table_is_sane(lengths[t], codes[t]))
+            return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "a Huffman table has a code longer than 16 bits, wider than its length, or lengths no prefix code can have");
+    ENTER_DEVICE(ctx);
     memcpy(ctx->lengths, lengths, sizeof ctx->lengths);
     memcpy(ctx->codes, codes, sizeof ctx->codes);
     return install_tables(ctx);
@@ -994,7 +829,7 @@ int jpeg_hip_build_huffman(jpeg_hip_ctx* ctx, const uint64_t h_hist[4][256]) {
     if (!ctx || !h_hist) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     if (!ctx->begun) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "call jpeg_hip_begin first");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     return build_tables(ctx, &h_hist[0][0]);
 }
 
@@ -1010,7 +845,7 @@ int jpeg_hip_emit_scan(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t out_capacity, 
     if (!ctx || !d_out || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     if (!ctx->transformed || !ctx->hasTables) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "emit needs coefficients and tables");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     return run_entropy(ctx, d_out, 0, out_capacity, 0, out_len);
 }
 
@@ -1018,7 +853,7 @@ int jpeg_hip_emit_scan_host(jpeg_hip_ctx* ctx, uint8_t* h_out, int64_t out_capac
     if (!ctx || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     if (!ctx->transformed || !ctx->hasTables) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "emit needs coefficients and tables");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     if (ctx->stagedScanLen < 0) {
         jpeg_hip_layout lay;
         int st = jpeg_hip_compute_layout(&ctx->prm, &lay);
@@ -1040,7 +875,7 @@ int jpeg_hip_emit_scan_host(jpeg_hip_ctx* ctx, uint8_t* h_out, int64_t out_capac
 int jpeg_hip_get_coefficients(jpeg_hip_ctx* ctx, int channel, int16_t* h_out, int64_t capacity_values) {
     if (!ctx || !h_out || channel < 0 || channel > 2) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (!ctx->transformed) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "no coefficients yet");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     const Geometry& g = ctx->geo;
     const int64_t perMcu = g.chanBlocks[channel];
     if (capacity_values < g.nMcu * perMcu * 64) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "coefficient buffer too small");
@@ -1091,7 +926,7 @@ int jpeg_hip_finish_band_start(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, ui
     if (!ctx || !d_out) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (!ctx->transformed) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "finish needs analyze");
     if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     int headerLen = 0;
     int st = fetch_hist_and_build(ctx, d_hist_sum, out_capacity, &headerLen);
     if (st != JPEG_HIP_OK) return st;
@@ -1104,7 +939,7 @@ int jpeg_hip_finish_band_start(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, ui
 int jpeg_hip_finish_band_wait(jpeg_hip_ctx* ctx, int64_t* out_len) {
     if (!ctx || !out_len) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     if (!ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "no jpeg_hip_finish_band_start to wait for");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     ctx->scanInFlight = false;
     return run_entropy_wait(ctx, out_len);
 }
@@ -1458,7 +1293,7 @@ extern "C" int jpeg_hip_encode_batch_host(jpeg_hip_ctx* ctx, const void* h_rgb, 
                                           int64_t image_stride_bytes, int count, const jpeg_hip_params* params,
                                           uint8_t* h_out, int64_t slot_bytes, int64_t* h_lens) {
     if (!ctx || !params || !h_rgb || !h_out || !h_lens) return JPEG_HIP_ERR_INVALID_ARGUMENT;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     const int64_t rowBytes = (int64_t)params->width * 3 * bytes_per_sample(sample_format);
     const int64_t packedStride = (rowBytes + 3) / 4 * 4;
     const int64_t packedImage = packedStride * params->height;
@@ -1638,14 +1473,14 @@ int jpeg_hip_decode_info(const uint8_t* h_jpeg, int64_t len, jpeg_hip_image_info
 int jpeg_hip_decode(jpeg_hip_ctx* ctx, const uint8_t* h_jpeg, int64_t len, uint8_t* d_rgb, int64_t stride_bytes,
                     int64_t capacity_bytes, jpeg_hip_image_info* info) {
     if (!ctx || !h_jpeg || !d_rgb) return JPEG_HIP_ERR_INVALID_ARGUMENT;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     return decode_to_device(ctx, h_jpeg, len, d_rgb, stride_bytes, capacity_bytes, info);
 }
 
 int jpeg_hip_decode_host(jpeg_hip_ctx* ctx, const uint8_t* h_jpeg, int64_t len, uint8_t* h_rgb, int64_t stride_bytes,
                          int64_t capacity_bytes, jpeg_hip_image_info* info) {
     if (!ctx || !h_jpeg || !h_rgb) return JPEG_HIP_ERR_INVALID_ARGUMENT;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     jpeg_hip_image_info local;
     int st = jpeg_hip_decode_info(h_jpeg, len, &local);
     if (st != JPEG_HIP_OK) return fail(ctx, st, "unsupported or damaged JPEG headers");
@@ -1678,7 +1513,7 @@ int jpeg_hip_psnr(jpeg_hip_ctx* ctx, const uint8_t* d_a, int64_t stride_a, const
                   int32_t width, int32_t height, double* mse, double* psnr) {
     if (!ctx || !d_a || !d_b || width < 1 || height < 1 || stride_a < (int64_t)width * 3 || stride_b < (int64_t)width * 3)
         return JPEG_HIP_ERR_INVALID_ARGUMENT;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx);
     HIP_TRY(ctx, ctx->decSum.ensure(8));
     HIP_TRY(ctx, launch_squared_error(d_a, stride_a, d_b, stride_b, width, height, (unsigned long long*)ctx->decSum.p,
                                       ctx->stream));

@@ -1,0 +1,1050 @@
+// Entropy stage of the MI355X (gfx950) JPEG encode hot path: symbol histograms, the
+// single-pass bit writer and byte stuffing.
+#include "device_common.h"
+#include "kernels.h"
+
+#include "jpegenc_hip.h"
+
+namespace jpeghip {
+
+// ----------------------------------------------------------------------------------------
+// Entropy stage, shared block walk.  A visitor sees the DC symbol, every AC symbol with
+// its amplitude bits, zero-run-length symbols and the end-of-block symbol, in scan order
+// (Encoder::calculateDCValues / calculateACValues, Encoder.cpp:260-352).
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ int bit_category(int v) {   // Encoder::lookupBitCategory, Encoder.cpp:354-366
+    const int a = v < 0 ? -v : v;
+    return 32 - __clz(a);   // __clz(0) == 32
+}
+
+// Number of leading bits equal to the sign bit (v_ffbh_i32; the compiler has no builtin for
+// it and expands __builtin_clrsb into several instructions).  Not for 0 and -1.
+__device__ __forceinline__ int leading_sign_bits(int x) {
+    int r;
+    asm("v_ffbh_i32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+__device__ __forceinline__ int coef_at(const u32 (&w)[32], int i) {
+    return (int)(short)(w[i >> 1] >> ((i & 1) * 16));
+}
+
+// Where a block sits in its image.  The block index inside one image fits 32 bits for every
+// legal JPEG (65535 x 65535 pixels are 2 * 10^8 blocks), which keeps the divisions cheap.
+struct BlockRole {
+    u32 mcu;       // MCU inside the image
+    int k;         // block inside the MCU
+    int c;         // channel
+    int back;      // blocks between this one and the previous block of its channel, 1..bpm
+    bool resets;   // first block of its channel in a restart interval: the DC predictor is 0
+};
+
+__device__ __forceinline__ BlockRole block_role(const KGeom& g, u32 bl) {
+    BlockRole r;
+    const u32 bpm = (u32)g.bpm;
+    r.mcu = bl / bpm;
+    r.k = (int)(bl - r.mcu * bpm);
+    r.c = r.k < g.off1 ? 0 : (r.k < g.off2 ? 1 : 2);
+    const int first = r.c == 0 ? 0 : (r.c == 1 ? g.off1 : g.off2);
+    const int last = (r.c == 0 ? g.off1 : (r.c == 1 ? g.off2 : g.bpm)) - 1;
+    r.back = r.k > first ? 1 : g.bpm - (last - first);
+    // One interval per image (no restarts, or a batch): only MCU 0 starts one.
+    const bool atStart = g.intervals == g.batch ? r.mcu == 0 : r.mcu % (u32)g.mcusPerInterval == 0;
+    r.resets = r.k == first && atStart;
+    return r;
+}
+
+// Block whose DC term the lane has to fetch from memory as predictor of block b: lanes hold
+// consecutive blocks (lane l: block b0 + l), the predecessor is at most one MCU back, so all
+// but the first `back` lanes of a wave get it from a neighbouring lane.  Lanes that need no
+// fetch name their own block, which keeps the address valid and the line in cache.
+__device__ __forceinline__ long long dc_predictor_source(const BlockRole& r, long long b) {
+    const int lane = threadIdx.x & 63;
+    return (lane >= r.back || r.resets) ? b : b - r.back;
+}
+
+// DC predictor (previous block of the same channel in scan order, 0 at the start of a
+// restart interval and of the band) from the lane's own DC term, its neighbours' and the
+// term fetched from dc_predictor_source().  Call with all lanes of the wave.
+__device__ __forceinline__ int dc_predictor_lanes(const BlockRole& r, int myDc, int fetchedDc, bool active) {
+    const int lane = threadIdx.x & 63;
+    const int fromLane = __shfl(myDc, (lane - r.back) & 63, 64);
+    if (!active || r.resets) return 0;
+    return lane >= r.back ? fromLane : fetchedDc;
+}
+
+template <class Visitor>
+__device__ __forceinline__ void walk_block(const u32 (&w)[32], int pred, Visitor& vis) {
+    const int diff = coef_at(w, 0) - pred;
+    const int dcat = bit_category(diff);
+    vis.dc(dcat, (u32)(diff < 0 ? diff - 1 : diff) & ((1u << dcat) - 1u));
+    int last = 0;   // index of the last non-zero coefficient seen (the DC term counts)
+    // Eight coefficients (one 16-byte load) at a time: groups that are all zero -- most of
+    // the high-frequency half of a typical block -- are skipped.  A zero coefficient costs
+    // nothing but the test: the run in front of a non-zero one is the distance to `last`.
+#pragma unroll
+    for (int grp = 0; grp < 8; ++grp) {
+        const u32 any = (grp == 0 ? (w[0] & 0xffff0000u) : w[4 * grp]) | w[4 * grp + 1] | w[4 * grp + 2] | w[4 * grp + 3];
+        if (any == 0) continue;
+#pragma unroll
+        for (int i = 8 * grp + (grp == 0 ? 1 : 0); i < 8 * grp + 8; ++i) {
+            const int v = coef_at(w, i);
+            if (v != 0) {
+                int run = i - 1 - last;
+                last = i;
+                if (run > 15) {
+                    vis.zrl(run >> 4);
+                    run &= 15;
+                }
+                // The amplitude bits are those of v, or of v - 1 (the one's complement of |v|)
+                // for a negative v; either way the category is the number of bits left
+                // after the redundant sign bits (never 0 or -1 here: v is not 0).
+                const int amp = v + (v >> 31);
+                const int cat = 32 - leading_sign_bits(amp);
+                vis.ac((run << 4) | cat, cat, (u32)amp & ((1u << cat) - 1u));
+            }
+        }
+    }
+    if (last != 63) vis.eob();
+}
+
+__device__ __forceinline__ void load_block(const int16_t* coef, long long b, u32 (&w)[32]) {
+    const uint4* src = (const uint4*)(coef + b * 64);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint4 t = src[i];
+        w[4 * i] = t.x;
+        w[4 * i + 1] = t.y;
+        w[4 * i + 2] = t.z;
+        w[4 * i + 3] = t.w;
+    }
+}
+
+constexpr int kEntThreads = 256;
+
+// ---- histograms -------------------------------------------------------------------------
+struct HistVisitor {
+    u32* dcHist;
+    u32* acHist;
+    __device__ __forceinline__ void dc(int cat, u32) { atomicAdd(&dcHist[cat], 1u); }
+    __device__ __forceinline__ void ac(int sym, int, u32) { atomicAdd(&acHist[sym], 1u); }
+    __device__ __forceinline__ void zrl(int n) { atomicAdd(&acHist[0xF0], (u32)n); }
+    __device__ __forceinline__ void eob() { atomicAdd(&acHist[0], 1u); }
+};
+
+// blockIdx.y is the image of the batch; a workgroup never mixes images, so its LDS counts
+// belong to one histogram set.
+__global__ __launch_bounds__(kEntThreads) void k_histogram(KGeom g, const int16_t* __restrict__ coef,
+                                                           u64* __restrict__ hist, HistogramExport ex) {
+    __shared__ u32 lh[4 * 256];   // DC-Y, DC-C, AC-Y, AC-C (Encoder.cpp:368-416)
+    __shared__ bool lastOne;
+    for (int i = threadIdx.x; i < 1024; i += kEntThreads) lh[i] = 0;
+    __syncthreads();
+    const int16_t* image = coef + (long long)blockIdx.y * g.blocksPerImage * 64;
+    const u32 blocks = (u32)g.blocksPerImage;
+    const u32 stride = gridDim.x * kEntThreads;
+    for (u32 bl = blockIdx.x * kEntThreads + threadIdx.x; __any(bl < blocks); bl += stride) {
+        const bool active = bl < blocks;
+        const u32 cur = active ? bl : blocks - 1;   // lanes past the end stay in step for the shuffle
+        const BlockRole role = block_role(g, cur);
+        u32 w[32];
+        load_block(image, cur, w);
+        const int fetched = image[dc_predictor_source(role, cur) * 64];
+        const int pred = dc_predictor_lanes(role, coef_at(w, 0), fetched, active);
+        if (active) {
+            const int t = role.c == 0 ? 0 : 1;
+            HistVisitor vis{lh + 256 * t, lh + 512 + 256 * t};
+            walk_block(w, pred, vis);
+        }
+    }
+    __syncthreads();
+    u64* mine = hist + (long long)blockIdx.y * 1024;
+    if (ex.host == nullptr) {
+        for (int i = threadIdx.x; i < 1024; i += kEntThreads)
+            if (lh[i] != 0) atomicAdd(&mine[i], (u64)lh[i]);
+        return;
+    }
+    // The workgroup that finishes last hands the complete histograms to the host.  No
+    // fences (a release at device scope writes the whole L2 back, once per workgroup): the
+    // additions return their old values, so they have been performed when the workgroup
+    // counts itself off, and the last one reads the sums where the additions were made.
+    // The counter is never reset: the launcher tells which value the last one will see.
+    u64 old[1024 / kEntThreads];
+#pragma unroll
+    for (int k = 0; k < 1024 / kEntThreads; ++k) {   // all in flight before the first is waited for
+        const u32 v = lh[k * kEntThreads + threadIdx.x];
+        old[k] = v != 0 ? atomicAdd(&mine[k * kEntThreads + threadIdx.x], (u64)v) : 0;
+    }
+    u64 seen = 0;
+#pragma unroll
+    for (int k = 0; k < 1024 / kEntThreads; ++k) seen |= old[k];
+    // `seen` is there to be waited for, in front of the barrier: a store that depends on it
+    // (under a condition that never holds) cannot move behind.
+    if (seen == ~0ull) lh[0] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) lastOne = atomicAdd(ex.counter, 1ull) + 1 == ex.expected;
+    __syncthreads();
+    if (!lastOne) return;
+    for (int i = threadIdx.x; i < 1024; i += kEntThreads)
+        ex.host[i] = __hip_atomic_load(&hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Zeroes n 8-byte words.  A kernel rather than hipMemsetAsync: a launch costs the host a
+// few microseconds, a memset call several times that.
+__global__ __launch_bounds__(256) void k_zero_words(u64* __restrict__ p, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] = 0;
+}
+
+hipError_t launch_clear_histograms(unsigned long long* d_hist, int images, hipStream_t s) {
+    const long long words = 1024LL * images;
+    hipLaunchKernelGGL(k_zero_words, dim3((unsigned)((words + 255) / 256 > 1024 ? 1024 : (words + 255) / 256)), dim3(256), 0,
+                       s, d_hist, words);
+    return hipGetLastError();
+}
+
+hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, bool clear,
+                            HistogramExport* ex) {
+    if (clear) {
+        const hipError_t e = launch_clear_histograms(d_hist, g.batch, s);
+        if (e != hipSuccess) return e;
+    }
+    // Every workgroup takes the same number of 256-block passes.
+    const long long passes = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
+    // A workgroup ends with a flush of up to 1024 counters: a mid-sized image is better off
+    // with two passes per workgroup than with twice the workgroups (4K 4:4:4: 40 -> 26 us),
+    // a small one needs every workgroup it can get.
+    long long cap = g.batch > 1 ? (4096 / g.batch > 8 ? 4096 / g.batch : 8) : 2048;
+    if (g.batch == 1 && passes / 2 < cap) cap = passes / 2 > 256 ? passes / 2 : 256;
+    const long long rounds = (passes + cap - 1) / cap;
+    long long grid = (passes + rounds - 1) / rounds;
+    if (grid < 1) grid = 1;
+    HistogramExport none = {nullptr, 0, nullptr};
+    if (ex != nullptr && g.batch == 1) ex->expected += (unsigned long long)grid;   // what the counter reads when all are done
+    hipLaunchKernelGGL(k_histogram, dim3((unsigned)grid, (unsigned)g.batch), dim3(kEntThreads), 0, s, g, d_coef, d_hist,
+                       ex != nullptr && g.batch == 1 ? *ex : none);
+    return hipGetLastError();
+}
+
+// ---- bit lengths -------------------------------------------------------------------------
+// Bits a block occupies in the stream under the given tables.
+struct LengthVisitor {
+    const u32* dcTab;
+    const u32* acTab;
+    u32 bits;
+    __device__ __forceinline__ void dc(int cat, u32) { bits += (dcTab[cat] >> 16) + cat; }
+    __device__ __forceinline__ void ac(int sym, int cat, u32) { bits += (acTab[sym] >> 16) + cat; }
+    __device__ __forceinline__ void zrl(int n) { bits += n * (acTab[0xF0] >> 16); }
+    __device__ __forceinline__ void eob() { bits += acTab[0] >> 16; }
+};
+
+// ---- workgroup scan ----------------------------------------------------------------------
+constexpr int kScanThreads = 256;
+
+__device__ __forceinline__ u64 wave_inclusive_scan(u64 v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Exclusive scan of one value per thread over a 256-thread workgroup; returns the
+// exclusive prefix and the workgroup total.  lds: 4 values.
+__device__ __forceinline__ u64 block_exclusive_scan(u64 v, u64* lds, u64& total) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u64 inc = wave_inclusive_scan(v);
+    __syncthreads();
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    u64 base = 0;
+    u64 sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanThreads / 64; ++i) {
+        if (i < wave) base += lds[i];
+        sum += lds[i];
+    }
+    total = sum;
+    return base + inc - v;
+}
+
+// ---- restart intervals -------------------------------------------------------------------
+// The unstuffed stream holds, per interval, an RSTn marker (every interval but the image's
+// first) and the interval's bit string padded to a whole byte; the band that ends the
+// image appends EOI.  Markers travel inside the stream so that the stuffing pass needs no
+// interval bookkeeping; it recognises them by position (is_marker_ff).
+__device__ __forceinline__ int interval_marker_bytes(const KGeom& g, long long k) {
+    return g.batch == 1 && g.firstInterval + k > 0 ? 2 : 0;
+}
+
+// Does EOI follow interval k?  The last interval of a band that ends its image; in a batch
+// every interval is a whole image.
+__device__ __forceinline__ bool interval_has_eoi(const KGeom& g, long long k) {
+    return g.writeEoi && (g.batch > 1 || k == g.intervals - 1);
+}
+
+// ---- bit writer ------------------------------------------------------------------------
+// One thread per block appends its codes MSB first.  A workgroup's 256 blocks cover one
+// contiguous bit range; it is assembled in LDS (native word order, ds_or for the words two
+// blocks share) and copied out byte swapped with coalesced stores, so that memory holds the
+// big-endian bit string BitBuffer::pushBits builds (BitBuffer.cpp:128-204).  Only the
+// range's first and last word are merged into the zeroed buffer with atomicOr.  Ranges too
+// long for the LDS stage are written straight to memory.
+constexpr int kEmitStageShort = 2048;   // stage words of a tile of short blocks (8 bytes per block on average)
+constexpr int kEmitStageLong = 6144;    // ... of long blocks (up to 96 bytes per block on average)
+
+// Where a lane's bits go: the LDS stage (native order) or the global stream (swapped).
+struct BitTarget {
+    u32* words;
+    long long bias;   // index of the stream word that words[0] stands for
+    bool swap;
+    __device__ __forceinline__ void or_word(long long index, u32 v) const {
+        if (v != 0) atomicOr(&words[index - bias], swap ? __builtin_bswap32(v) : v);
+    }
+    // ORs up to 32 bits, given left aligned in v, into the stream at bit position pos.
+    __device__ __forceinline__ void or32(u64 pos, u32 v) const {
+        const long long d = (long long)(pos >> 5);
+        const int sh = (int)(pos & 31);
+        or_word(d, v >> sh);
+        if (sh != 0) or_word(d + 1, v << (32 - sh));
+    }
+};
+
+// First walk: the block's bit string, starting at bit 0, into a few words of LDS private to
+// the lane, and its length.  A block longer than the private words is only measured.
+constexpr int kPrivWords = 8;
+constexpr int kPrivPitch = 9;   // odd, so that the lanes' words spread over the banks
+
+struct PrivateVisitor {
+    const u32* dcTab;
+    const u32* acTab;
+    u32* words;
+    u64 acc;    // pending bits, right aligned
+    int n;      // number of pending bits (< 32 between calls)
+    int word;   // words completed
+    __device__ __forceinline__ void put(u32 bits, int len) {
+        acc = (acc << len) | bits;
+        n += len;
+        if (n >= 32) {
+            if (word < kPrivWords) words[word] = (u32)(acc >> (n - 32));
+            ++word;
+            n -= 32;
+        }
+    }
+    __device__ __forceinline__ void dc(int cat, u32 amp) {
+        const u32 e = dcTab[cat];
+        put(((e & 0xffffu) << cat) | amp, (int)(e >> 16) + cat);
+    }
+    __device__ __forceinline__ void ac(int sym, int cat, u32 amp) {
+        const u32 e = acTab[sym];
+        put(((e & 0xffffu) << cat) | amp, (int)(e >> 16) + cat);
+    }
+    __device__ __forceinline__ void zrl(int cnt) {
+        const u32 e = acTab[0xF0];
+        for (int i = 0; i < cnt; ++i) put(e & 0xffffu, (int)(e >> 16));
+    }
+    __device__ __forceinline__ void eob() {
+        const u32 e = acTab[0];
+        put(e & 0xffffu, (int)(e >> 16));
+    }
+    __device__ __forceinline__ u32 finish() {   // returns the length in bits
+        if (n > 0 && word < kPrivWords) words[word] = (u32)(acc << (32 - n));
+        return (u32)(word * 32 + n);
+    }
+};
+
+// Second walk, for the blocks that did not fit their private words: straight to the target.
+struct EmitVisitor {
+    const u32* dcTab;
+    const u32* acTab;
+    BitTarget out;
+    long long word;   // index of the word being filled
+    u64 acc;          // pending bits, right aligned
+    int n;            // number of pending bits (< 32 between calls)
+    bool first;
+    __device__ __forceinline__ void flush_word() {
+        const u32 w = (u32)(acc >> (n - 32));
+        if (first) {
+            out.or_word(word, w);
+            first = false;
+        } else {
+            out.words[word - out.bias] = out.swap ? __builtin_bswap32(w) : w;
+        }
+        ++word;
+        n -= 32;
+    }
+    __device__ __forceinline__ void put(u32 bits, int len) {
+        acc = (acc << len) | bits;
+        n += len;
+        if (n >= 32) flush_word();
+    }
+    // Code and amplitude go in together: at most 16 + 11 bits on top of fewer than 32 pending.
+    __device__ __forceinline__ void dc(int cat, u32 amp) {
+        const u32 e = dcTab[cat];
+        put(((e & 0xffffu) << cat) | amp, (int)(e >> 16) + cat);
+    }
+    __device__ __forceinline__ void ac(int sym, int cat, u32 amp) {
+        const u32 e = acTab[sym];
+        put(((e & 0xffffu) << cat) | amp, (int)(e >> 16) + cat);
+    }
+    __device__ __forceinline__ void zrl(int cnt) {
+        const u32 e = acTab[0xF0];
+        for (int i = 0; i < cnt; ++i) put(e & 0xffffu, (int)(e >> 16));
+    }
+    __device__ __forceinline__ void eob() {
+        const u32 e = acTab[0];
+        put(e & 0xffffu, (int)(e >> 16));
+    }
+    __device__ __forceinline__ void finish() {
+        if (n > 0) out.or_word(word, (u32)(acc << (32 - n)));
+    }
+};
+
+// ---- single-pass bit writer --------------------------------------------------------------
+// Bit lengths, stream positions and the bit writer in one pass over the coefficients.  A
+// tile is 256 consecutive blocks of one image.  The stream position after a block is a
+// function of the position before it: P + bits, or, behind the last block of a restart
+// interval, roundup8(P + bits) + the marker that follows (the next interval's RSTn, or EOI).
+// A run of blocks composes to "P + h" (no interval ends inside) or "roundup8(P + h) + m",
+// an associative summary, so tiles chain with a decoupled look-back: every tile publishes
+// its summary as soon as its lengths are known, then its first wave reads the summaries of
+// its predecessors back to the nearest tile whose absolute position is already known.
+// Tiles take their numbers from a counter, so every predecessor of a running tile is
+// running or finished and the wait always ends.
+struct PosSummary {
+    u32 x;   // h, bit 31: an interval ends inside
+    u32 y;   // m
+};
+
+__device__ __forceinline__ PosSummary pos_combine(PosSummary a, PosSummary b) {   // a precedes b
+    PosSummary r;
+    if ((a.x >> 31) == 0) {
+        r.x = a.x + b.x;
+        r.y = b.y;
+    } else {
+        const u32 bh = b.x & 0x7fffffffu;
+        r.x = a.x;
+        r.y = (b.x >> 31) ? ((a.y + bh + 7u) & ~7u) + b.y : a.y + bh;
+    }
+    return r;
+}
+
+__device__ __forceinline__ u64 pos_apply(PosSummary s, u64 p) {
+    const u32 h = s.x & 0x7fffffffu;
+    return (s.x >> 31) ? ((p + h + 7) & ~7ull) + s.y : p + h;
+}
+
+constexpr u64 kTileAggregate = 1ull << 62, kTilePosition = 2ull << 62, kTilePayload = (1ull << 62) - 1;
+constexpr int kLookBackSpins = 1 << 18;
+
+__device__ __forceinline__ PosSummary shfl_down_summary(PosSummary v, int d, int lane) {
+    PosSummary o;
+    o.x = __shfl_down(v.x, d, 64);
+    o.y = __shfl_down(v.y, d, 64);
+    if (lane + d >= 64) o.x = o.y = 0;
+    return o;
+}
+
+// Absolute bit position at which tile `tile` starts; p0 is the position of the stream's
+// first block.  Called by all 64 lanes of one wave.  Returns false if a predecessor never
+// reported (cannot happen with ordered tile numbers; bounded so a fault cannot hang the GPU).
+__device__ __forceinline__ bool look_back(const u64* state, long long tile, u64 p0, u64& position) {
+    const int lane = threadIdx.x & 63;
+    PosSummary acc = {0u, 0u};
+    int spins = 0;
+    for (long long base = tile - 1;; base -= 64) {
+        const long long idx = base - lane;
+        u64 st = idx < 0 ? (kTilePosition | p0) : __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__ballot((st >> 62) == 0) != 0) {
+            if (++spins > kLookBackSpins) return false;
+            __builtin_amdgcn_s_sleep(2);
+            if ((st >> 62) == 0) st = __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const u64 known = __ballot((st >> 62) == 2);
+        const int nearest = known ? __builtin_ctzll(known) : 64;   // lanes below it hold summaries only
+        PosSummary v = {0u, 0u};
+        if (lane < nearest) {
+            v.x = (u32)((st & kTilePayload) >> 30);
+            v.y = (u32)(st & 0x3fffffffu);
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) v = pos_combine(shfl_down_summary(v, d, lane), v);   // older tiles first
+        PosSummary window;
+        window.x = __shfl(v.x, 0, 64);
+        window.y = __shfl(v.y, 0, 64);
+        acc = pos_combine(window, acc);
+        if (known) {
+            const u64 p = __shfl(st & kTilePayload, nearest, 64);
+            position = pos_apply(acc, p);
+            return true;
+        }
+    }
+}
+
+// kPrivate: blocks are short on average (photographic content), so the first walk keeps
+// each block's bits in a few private LDS words and the second walk is a copy; otherwise the
+// first walk only measures and every block is walked twice.
+template <bool kPrivate>
+__global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int16_t* __restrict__ coef,
+                                                             const u32* __restrict__ tables, u64* __restrict__ state,
+                                                             u64* __restrict__ ivOff, u64* __restrict__ result,
+                                                             u32* __restrict__ words, u64* __restrict__ hostResult) {
+    __shared__ u32 tab[4 * 256];
+    constexpr int kStageWords = kPrivate ? kEmitStageShort : kEmitStageLong;
+    __shared__ u32 stage[kStageWords];
+    __shared__ u64 span[2];
+    __shared__ PosSummary waveSum[kEntThreads / 64];
+    __shared__ u32 priv[kPrivate ? kEntThreads * kPrivPitch : 1];
+    __shared__ u64 tileStart;
+    __shared__ long long tileNo;
+    const long long tilesPerImage = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
+    const long long tiles = tilesPerImage * g.batch;
+    u64* counter = state + tiles;
+    if (threadIdx.x == 0) tileNo = (long long)atomicAdd((unsigned long long*)counter, 1ull);
+    __syncthreads();
+    // Tile and block numbers fit 32 bits (see BlockRole); the tile number is the same for
+    // the whole workgroup.
+    const u32 tile = __builtin_amdgcn_readfirstlane((u32)tileNo);
+    const u32 image = g.batch > 1 ? tile / (u32)tilesPerImage : 0u;
+    const u32 bl = (tile - image * (u32)tilesPerImage) * kEntThreads + threadIdx.x;
+    const long long b = (long long)image * g.blocksPerImage + bl;
+    const bool active = bl < (u32)g.blocksPerImage;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long blocksPerInterval = g.mcusPerInterval * g.bpm;
+    const BlockRole role = block_role(g, active ? bl : (u32)g.blocksPerImage - 1);
+
+    u32 w[32];
+    int fetchedDc = 0;
+    if (active) {   // in flight while the tables are staged
+        load_block(coef, b, w);
+        fetchedDc = coef[dc_predictor_source(role, b) * 64];
+    }
+    const u32* myTables = tables + image * g.tableStride;
+    for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = myTables[i];
+    __syncthreads();
+
+    long long iv = 0;
+    bool firstOfInterval = false, lastOfInterval = false;
+    PosSummary mine = {0u, 0u};
+    u32 bits = 0;
+    const int c = role.c;
+    const int pred = dc_predictor_lanes(role, active ? coef_at(w, 0) : 0, fetchedDc, active);
+    if (active) {
+        iv = g.intervals == g.batch ? (long long)image : (long long)(role.mcu / (u32)g.mcusPerInterval);
+        const long long ivFirstBlock = iv * blocksPerInterval;
+        long long ivEnd = ivFirstBlock + blocksPerInterval;
+        if (ivEnd > g.totalBlocks) ivEnd = g.totalBlocks;
+        firstOfInterval = b == ivFirstBlock;
+        lastOfInterval = b == ivEnd - 1;
+        const int t = c == 0 ? 0 : 1;
+        if (kPrivate) {
+            PrivateVisitor pv{tab + 256 * t, tab + 512 + 256 * t, priv + threadIdx.x * kPrivPitch, 0, 0, 0};
+            walk_block(w, pred, pv);
+            bits = pv.finish();
+        } else {
+            LengthVisitor len{tab + 256 * t, tab + 512 + 256 * t, 0u};
+            walk_block(w, pred, len);
+            bits = len.bits;
+        }
+        mine.x = bits;
+        if (lastOfInterval) {
+            mine.x |= 0x80000000u;
+            mine.y = iv + 1 < g.intervals ? 8u * (u32)interval_marker_bytes(g, iv + 1) : 0u;
+            if (interval_has_eoi(g, iv)) mine.y += 16u;
+        }
+    }
+    // Inclusive scan of the summaries over the workgroup.
+    PosSummary inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        PosSummary o;
+        o.x = __shfl_up(inc.x, d, 64);
+        o.y = __shfl_up(inc.y, d, 64);
+        if (lane >= d) inc = pos_combine(o, inc);
+    }
+    if (lane == 63) waveSum[wave] = inc;
+    __syncthreads();
+    PosSummary before = {0u, 0u}, whole = {0u, 0u};
+#pragma unroll
+    for (int i = 0; i < kEntThreads / 64; ++i) {
+        if (i < wave) before = pos_combine(before, waveSum[i]);
+        whole = pos_combine(whole, waveSum[i]);
+    }
+    PosSummary excl;
+    excl.x = __shfl_up(inc.x, 1, 64);
+    excl.y = __shfl_up(inc.y, 1, 64);
+    if (lane == 0) excl.x = excl.y = 0;
+    excl = pos_combine(before, excl);
+
+    const u64 p0 = 8ull * (u64)interval_marker_bytes(g, 0);
+    if (wave == 0) {
+        if (tile > 0 && lane == 0)
+            __hip_atomic_store(state + tile, kTileAggregate | ((u64)whole.x << 30) | whole.y, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        u64 start = p0;
+        bool ok = true;
+        if (tile > 0) ok = look_back(state, tile, p0, start);
+        if (lane == 0) {
+            if (!ok) {
+                start = p0;
+                result[1] = 2;
+                if (hostResult) hostResult[2] = 2;
+            }
+            __hip_atomic_store(state + tile, kTilePosition | pos_apply(whole, start), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            tileStart = start;
+        }
+    }
+    __syncthreads();
+
+    u64 pos = 0;
+    int padBits = 0;
+    u32 leadMarker = 0;
+    bool tailEoi = false;
+    if (active) {
+        pos = pos_apply(excl, tileStart);
+        u64 begin = pos;
+        u64 end = pos + bits;
+        if (firstOfInterval) {
+            const int mk = interval_marker_bytes(g, iv);
+            if (mk) {
+                leadMarker = 0xffd0u + (u32)((g.firstInterval + iv - 1) & 7);
+                begin -= 16;
+            }
+            ivOff[iv] = begin >> 3;
+        }
+        if (lastOfInterval) {   // pad the interval to a byte boundary (BitBuffer.cpp:12-16)
+            padBits = (int)((8 - (end & 7)) & 7);
+            end += padBits;
+            if (interval_has_eoi(g, iv)) {
+                tailEoi = true;
+                end += 16;
+            }
+            if (b == g.totalBlocks - 1) {
+                const u64 bytes = end >> 3;
+                ivOff[g.intervals] = bytes;
+                result[2] = bytes;
+                result[3] = (bytes + kStuffChunk - 1) / kStuffChunk;
+            }
+        }
+        if (threadIdx.x == 0) span[0] = begin;
+        if (threadIdx.x == kEntThreads - 1 || bl == g.blocksPerImage - 1) span[1] = end;
+        pos = begin;
+    }
+    __syncthreads();
+    const u64 wordBase = span[0] >> 5;
+    const u64 nWords = ((span[1] + 31) >> 5) - wordBase;
+    const bool staged = nWords <= (u64)kStageWords;
+    if (staged) {
+        for (u32 i = threadIdx.x; i < (u32)nWords; i += kEntThreads) stage[i] = 0;
+        __syncthreads();
+    }
+    if (active) {
+        const BitTarget out{staged ? stage : words, staged ? (long long)wordBase : 0, !staged};
+        const u64 start = pos + (leadMarker ? 16 : 0);   // first bit of the block itself
+        if (leadMarker) out.or32(pos, leadMarker << 16);
+        if (kPrivate && bits <= (u32)(kPrivWords * 32)) {
+            const u32* mine32 = priv + threadIdx.x * kPrivPitch;
+#pragma unroll
+            for (int k = 0; k < kPrivWords; ++k)
+                if ((u32)(32 * k) < bits) out.or32(start + 32 * k, mine32[k]);
+        } else {
+            const int t = c == 0 ? 0 : 1;
+            EmitVisitor vis{tab + 256 * t, tab + 512 + 256 * t, out, (long long)(start >> 5), 0, (int)(start & 31), true};
+            walk_block(w, pred, vis);
+            vis.finish();
+        }
+        if (padBits != 0 && g.padOnes) out.or32(start + bits, ((1u << padBits) - 1u) << (32 - padBits));
+        if (tailEoi) out.or32(start + bits + padBits, 0xffd9u << 16);
+    }
+    if (staged) {
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < (u32)nWords; i += kEntThreads) {
+            const u32 v = __builtin_bswap32(stage[i]);
+            if (i == 0 || i == (u32)nWords - 1) {
+                if (v != 0) atomicOr(&words[wordBase + i], v);
+            } else {
+                words[wordBase + i] = v;
+            }
+        }
+    }
+}
+
+// ---- byte stuffing -----------------------------------------------------------------------
+__device__ __forceinline__ int count_ff(u32 w) {
+    // A byte is 0xFF iff all its bits are set: fold the 8 bits of every byte into bit 0.
+    u32 t = w & (w >> 4);
+    t &= t >> 2;
+    t &= t >> 1;
+    return __popc(t & 0x01010101u);
+}
+
+// Is the 0xFF at byte position i (followed by `next`) the first byte of a marker that the
+// bit writer placed in the stream?  Only reached for FF D0..D7 / FF D9 pairs, i.e. rarely.
+__device__ __forceinline__ bool is_marker_ff(const KGeom& g, const u64* __restrict__ ivOff, u64 bytes, u64 i,
+                                             uint8_t next) {
+    (void)bytes;
+    if (next != 0xd9 && (next < 0xd0 || next > 0xd7)) return false;
+    long long lo = 0, hi = g.intervals - 1;   // last interval starting at or before i
+    while (lo < hi) {
+        const long long mid = (lo + hi + 1) >> 1;
+        if (ivOff[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    if (next == 0xd9) return interval_has_eoi(g, lo) && i + 2 == ivOff[lo + 1];
+    return ivOff[lo] == i && interval_marker_bytes(g, lo) != 0;
+}
+
+__device__ __forceinline__ u32 ff_bits(u32 w) {   // bit k: byte k of w is 0xFF
+    u32 t = w & (w >> 4);
+    t &= t >> 2;
+    t &= t >> 1;
+    // The flags sit at bits 0, 8, 16, 24; the product brings them to bits 24..27 (no two of
+    // the sixteen partial products meet, so nothing carries).
+    return ((t & 0x01010101u) * 0x01020408u) >> 24;
+}
+
+// Loads 16 stream bytes (plus one of lookahead) and returns a 16-bit mask of the data bytes
+// equal to 0xFF, i.e. those that need a 0x00 behind them (BitBuffer.cpp:156-161, 171-176,
+// 190-195).  Only bytes of the stream count.
+__device__ __forceinline__ u32 stuff_mask(const KGeom& g, const uint8_t* __restrict__ buf,
+                                          const u64* __restrict__ ivOff, u64 bytes, long long i0, uint4& q) {
+    q = *(const uint4*)(buf + i0);
+    u32 ff = ff_bits(q.x) | (ff_bits(q.y) << 4) | (ff_bits(q.z) << 8) | (ff_bits(q.w) << 12);
+    const long long left = (long long)bytes - i0;
+    if (left < 16) ff &= left > 0 ? (1u << (int)left) - 1u : 0u;
+    if (ff == 0) return 0;
+    // One round per 0xFF byte of the piece (one or two as a rule) instead of one per byte.
+    const u64 lo = (u64)q.x | ((u64)q.y << 32), hi = (u64)q.z | ((u64)q.w << 32);
+    const u32 last = (u32)buf[i0 + 16];
+    u32 mask = ff;
+    for (u32 todo = ff; todo != 0; todo &= todo - 1) {
+        const int j = __builtin_ctz(todo), n = j + 1;
+        const uint8_t nxt = (uint8_t)(n < 8 ? lo >> (8 * n) : (n < 16 ? hi >> (8 * (n - 8)) : (u64)last));
+        const bool maybe = (nxt >= 0xd0 && nxt <= 0xd7) || nxt == 0xd9;
+        if (maybe && is_marker_ff(g, ivOff, bytes, (u64)(i0 + j), nxt)) mask &= ~(1u << j);
+    }
+    return mask;
+}
+
+// One wave per 4 KiB chunk: four 16-byte pieces per lane in flight, a shuffle reduction, no
+// barriers.
+constexpr int kChunkGroup = 64;   // chunks whose counts are also kept as one sum
+
+__global__ __launch_bounds__(256) void k_count_ff(KGeom g, const uint8_t* __restrict__ buf,
+                                                  const u64* __restrict__ ivOff, const u64* __restrict__ result,
+                                                  u32* __restrict__ ffCount) {
+    const u64 bytes = result[2];
+    const long long chunks = (long long)((bytes + kStuffChunk - 1) / kStuffChunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long long ch = (long long)blockIdx.x * 4 + wave; ch < chunks; ch += (long long)gridDim.x * 4) {
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kStuffChunk / 1024; ++k) {
+            const long long i0 = ch * kStuffChunk + k * 1024 + lane * 16;
+            if ((u64)i0 < bytes) {
+                uint4 q;
+                cnt += __popc(stuff_mask(g, buf, ivOff, bytes, i0, q));
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+        if (lane == 0) ffCount[ch] = (u32)cnt;
+    }
+}
+
+// For long streams: the counts of kChunkGroup consecutive chunks added up, one wave per sum.
+__global__ __launch_bounds__(256) void k_group_sums(const u32* __restrict__ ffCount, const u64* __restrict__ result,
+                                                    u64* __restrict__ groupSum) {
+    static_assert(kChunkGroup == 64, "one lane per chunk of a group");
+    const long long chunks = (long long)((result[2] + kStuffChunk - 1) / kStuffChunk);
+    const int lane = threadIdx.x & 63;
+    const long long grp = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (grp * kChunkGroup >= chunks) return;
+    const long long c = grp * kChunkGroup + lane;
+    u64 sum = c < chunks ? ffCount[c] : 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane == 0) groupSum[grp] = sum;
+}
+
+// Stuffing bytes in front of chunk ch, added up by the 256 threads of a workgroup from the
+// per-chunk counts; cheap enough once per workgroup that the stream needs no device-wide
+// scan kernel.  Long streams (groupSum set) have the counts of whole groups added up already.
+__device__ __forceinline__ u64 chunk_prefix(const u64* __restrict__ groupSum, const u32* __restrict__ ffCount,
+                                            long long ch, u64* lds) {
+    u64 v = 0;
+    if (groupSum != nullptr) {
+        const long long grp = ch / kChunkGroup;
+        for (long long i = threadIdx.x; i < grp; i += 256) v += groupSum[i];
+        const long long c = grp * kChunkGroup + threadIdx.x;
+        if (threadIdx.x < kChunkGroup && c < ch) v += ffCount[c];
+    } else {
+        // Eight loads in flight per thread: one after the other they would cost a memory
+        // latency each.
+        for (long long i0 = threadIdx.x; i0 < ch; i0 += 8 * 256) {
+            u32 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = i0 + k * 256 < ch ? ffCount[i0 + k * 256] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += t[k];
+        }
+    }
+    u64 total;
+    block_exclusive_scan(v, lds, total);
+    __syncthreads();   // lds is free again
+    return total;
+}
+
+// Copies the stream to the output with the stuffing bytes inserted.  A workgroup's 4 KiB
+// chunk becomes one contiguous output range, which is laid out in LDS at the output's own
+// 4-byte phase and stored as dwords.  In a batch the stream of image k goes behind header k
+// in slot k; a chunk that holds the end of one image and the start of the next is written
+// byte by byte instead.
+constexpr int kStuffStageBytes = 2 * kStuffChunk + 16;
+
+// Interval (= image of a batch) that contains stream byte i.
+__device__ __forceinline__ long long interval_of(const KGeom& g, const u64* __restrict__ ivOff, u64 i) {
+    long long lo = 0, hi = g.intervals - 1;
+    while (lo < hi) {
+        const long long mid = (lo + hi + 1) >> 1;
+        if (ivOff[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// Output position of stream byte i of image k, given the stuffing bytes in front of it.
+__device__ __forceinline__ long long batch_position(const BatchOutput& bo, const u64* __restrict__ ivOff, long long k,
+                                                    u64 i, u64 ffBefore) {
+    return k * bo.slotBytes + (long long)bo.hdrLen[k] + (long long)(i - ivOff[k]) + (long long)(ffBefore - bo.ffStart[k]);
+}
+
+template <bool kBatch>
+__global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __restrict__ buf,
+                                                     const u64* __restrict__ ivOff, const u32* __restrict__ ffCount,
+                                                     const u64* __restrict__ groupSum, u64* __restrict__ result,
+                                                     uint8_t* __restrict__ out, long long prefixLen,
+                                                     long long outCapacity, BatchOutput bo, u64* __restrict__ hostResult) {
+    __shared__ u64 lds[4];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStuffStageBytes];
+    const u64 bytes = result[2];
+    const long long chunks = (long long)((bytes + kStuffChunk - 1) / kStuffChunk);
+    // A workgroup takes a run of consecutive chunks: the stuffing bytes in front of the
+    // first come from the counting pass, those in front of the others from its own work.
+    // The runs differ by one chunk at most, so that every workgroup of the grid has work.
+    const long long chFirst = chunks * blockIdx.x / gridDim.x;
+    const long long chEnd = chunks * (blockIdx.x + 1) / gridDim.x;
+    if (chFirst >= chEnd) return;
+    u64 ffBefore = chunk_prefix(groupSum, ffCount, chFirst, lds);
+    for (long long ch = chFirst; ch < chEnd; ++ch) {
+        const long long c0 = ch * kStuffChunk;
+        const long long i0 = c0 + (long long)threadIdx.x * 16;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        int valid = 0;
+        u32 mask = 0;
+        if ((u64)i0 < bytes) {
+            valid = (int)(bytes - (u64)i0 < 16 ? bytes - (u64)i0 : 16);
+            mask = stuff_mask(g, buf, ivOff, bytes, i0, q);
+        }
+        u64 total;
+        const u64 local = block_exclusive_scan((u64)(valid + __popc(mask)), lds, total);
+        // Output range of the chunk: one piece, except for a batch chunk that spans images.
+        long long base, limit;
+        bool onePiece = true;
+        if (kBatch) {
+            const long long k = interval_of(g, ivOff, (u64)c0);
+            const u64 cEnd = (u64)c0 + kStuffChunk < bytes ? (u64)c0 + kStuffChunk : bytes;
+            onePiece = cEnd <= ivOff[k + 1];
+            base = batch_position(bo, ivOff, k, (u64)c0, ffBefore);
+            limit = (k + 1) * bo.slotBytes;
+        } else {
+            base = prefixLen + c0 + (long long)ffBefore;
+            limit = outCapacity;
+        }
+        if (onePiece) {
+            if (base + (long long)total > limit) {
+                if (threadIdx.x == 0) {
+                    result[1] = 1;
+                    if (hostResult) hostResult[1] = 1;
+                }
+            } else {
+                const int phase = (int)((uintptr_t)(out + base) & 3);
+                if (valid > 0) {
+                    uint8_t* dst = stage + phase + (int)local;
+                    const u32 ws[4] = {q.x, q.y, q.z, q.w};
+                    if (mask == 0 && valid == 16) {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) dst[j] = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
+                    } else {
+                        int o = 0;
+                        for (int j = 0; j < valid; ++j) {
+                            dst[o++] = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
+                            if ((mask >> j) & 1) dst[o++] = 0x00;
+                        }
+                    }
+                }
+                __syncthreads();
+                const int nTot = phase + (int)total;
+                uint8_t* dst = out + base - phase;   // 4-byte aligned
+                for (int d = threadIdx.x; d * 4 < nTot; d += 256) {
+                    const int lo4 = d * 4;
+                    if (lo4 >= phase && lo4 + 4 <= nTot) {
+                        *(u32*)(dst + lo4) = *(const u32*)(stage + lo4);
+                    } else {
+                        for (int bb = lo4 < phase ? phase : lo4; bb < lo4 + 4 && bb < nTot; ++bb) dst[bb] = stage[bb];
+                    }
+                }
+            }
+        } else if (valid > 0) {
+            // Batch chunk across an image boundary: every byte finds its own slot.
+            const u32 ws[4] = {q.x, q.y, q.z, q.w};
+            long long k = interval_of(g, ivOff, (u64)i0);
+            u64 ff = ffBefore + (local - (u64)((long long)i0 - c0));   // stuffing bytes in front of byte i0
+            bool overflow = false;
+            for (int j = 0; j < valid; ++j) {
+                const u64 i = (u64)(i0 + j);
+                while (i >= ivOff[k + 1]) ++k;
+                const long long pos = batch_position(bo, ivOff, k, i, ff);
+                const int extra = (mask >> j) & 1;
+                if (pos + 1 + extra <= (k + 1) * bo.slotBytes) {
+                    out[pos] = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
+                    if (extra) out[pos + 1] = 0x00;
+                } else {
+                    overflow = true;
+                }
+                ff += extra;
+            }
+            if (overflow) result[1] = 1;
+        }
+        if (!kBatch && ch == chunks - 1 && threadIdx.x == 0) {
+            result[0] = (u64)(base + (long long)total);
+            if (hostResult) hostResult[0] = (u64)(base + (long long)total);
+        }
+        const u64 chunkBytes = bytes - (u64)c0 < (u64)kStuffChunk ? bytes - (u64)c0 : (u64)kStuffChunk;
+        ffBefore += total - chunkBytes;   // what the chunk wrote beyond its own bytes
+        __syncthreads();
+    }
+}
+
+// Batch: stuffing bytes in front of each image's stream (and, for k = batch, in total).
+__global__ __launch_bounds__(256) void k_image_ff_start(KGeom g, const uint8_t* __restrict__ buf,
+                                                        const u64* __restrict__ ivOff, const u32* __restrict__ ffCount,
+                                                        const u64* __restrict__ groupSum,
+                                                        const u64* __restrict__ result, u64* __restrict__ ffStart) {
+    __shared__ u64 lds[4];
+    const u64 bytes = result[2];
+    const long long k = blockIdx.x;
+    const u64 pos = ivOff[k];
+    const long long ch = (long long)(pos / kStuffChunk);
+    const long long i0 = ch * kStuffChunk + (long long)threadIdx.x * 16;
+    int cnt = 0;
+    if ((u64)i0 < pos) {
+        uint4 q;
+        u32 mask = stuff_mask(g, buf, ivOff, bytes, i0, q);
+        const u64 span = pos - (u64)i0;
+        if (span < 16) mask &= (1u << span) - 1u;
+        cnt = __popc(mask);
+    }
+    u64 total;
+    block_exclusive_scan((u64)cnt, lds, total);
+    __syncthreads();
+    const u64 before = chunk_prefix(groupSum, ffCount, ch, lds);
+    if (threadIdx.x == 0) ffStart[k] = before + total;
+}
+
+// Batch: header k to the front of slot k.
+__global__ __launch_bounds__(256) void k_copy_headers(BatchOutput bo) {
+    const long long k = blockIdx.x;
+    const uint8_t* src = bo.hdr + k * bo.hdrPitch;
+    uint8_t* dst = bo.out + k * bo.slotBytes;
+    const u32 n = bo.hdrLen[k];
+    for (u32 i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+
+// Everything the single-pass bit writer and the stuffing pass expect to find cleared, in one
+// launch: the reachable part of the unstuffed stream, the tile states with their counter,
+// the result record.  Also moves the file header from its staging place to the output.
+__global__ __launch_bounds__(256) void k_prepare_entropy(uint4* __restrict__ stream, long long stream16,
+                                                         u64* __restrict__ tileState, long long tileWords,
+                                                         u64* __restrict__ result, const uint8_t* __restrict__ hdr,
+                                                         int hdrLen, uint8_t* __restrict__ out,
+                                                         const u32* __restrict__ pending, u32* __restrict__ tables) {
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, step = (long long)gridDim.x * 256;
+    if (pending != nullptr) {
+        // Tables and header still sit in pinned host memory: bring them over (the device
+        // copy serves later launches) and take the header for the output from there.
+        const int words = 1024 + (hdrLen + 3) / 4;
+        for (long long i = tid; i < words; i += step) tables[i] = pending[i];
+        hdr = (const uint8_t*)(pending + 1024);
+    }
+    for (long long i = tid; i < stream16; i += step) stream[i] = make_uint4(0, 0, 0, 0);
+    for (long long i = tid; i < tileWords; i += step) tileState[i] = 0;
+    if (tid < 4) result[tid] = 0;
+    for (long long i = tid; i < hdrLen; i += step) out[i] = hdr[i];
+}
+
+static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const u32* d_tables,
+                                    const EntropyWorkspace& ws, uint8_t* d_out, long long prefixLen,
+                                    long long outCapacity, const BatchOutput* bo, hipStream_t s) {
+    const long long tilesPerImage = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
+    const long long tileCount = tilesPerImage * g.batch;
+    // The bit writer ORs into the stream, so the part it can reach starts out as zeros.
+    long long zero = ws.streamBound < 0 ? ws.unstuffedCap : (ws.streamBound + kStuffChunk + 63) / 16 * 16;
+    if (zero > ws.unstuffedCap) zero = ws.unstuffedCap;
+    long long prepGrid = zero / 16 / (256 * 4);
+    prepGrid = prepGrid < 1 ? 1 : (prepGrid > 2048 ? 2048 : prepGrid);
+    // Chunks the stream can have at most: from the bound that was cleared.
+    long long chunkBound = zero / kStuffChunk + 1;
+    if (chunkBound > ws.maxChunks) chunkBound = ws.maxChunks;
+    hipLaunchKernelGGL(k_prepare_entropy, dim3((unsigned)prepGrid), dim3(256), 0, s, (uint4*)ws.unstuffed, zero / 16,
+                       ws.tileState, tileCount + 1, ws.result, ws.header, bo ? 0 : ws.headerLen, d_out,
+                       bo ? nullptr : ws.pendingTables, const_cast<u32*>(d_tables));
+    // Long blocks (noise, q=100) do not fit the private words; unknown lengths count as short.
+    const bool shortBlocks = ws.avgBlockBits <= 128;
+    if (shortBlocks)
+        hipLaunchKernelGGL(k_encode_bits<true>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
+                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult);
+    else
+        hipLaunchKernelGGL(k_encode_bits<false>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
+                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult);
+    long long chunkGrid = chunkBound < 4096 ? chunkBound : 4096;
+    if (chunkGrid < 1) chunkGrid = 1;
+    long long countGrid = (chunkBound + 3) / 4;
+    countGrid = countGrid < 1 ? 1 : (countGrid > 4096 ? 4096 : countGrid);
+    hipLaunchKernelGGL(k_count_ff, dim3((unsigned)countGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.result,
+                       ws.ffCount);
+    // Up to this many chunks a workgroup adds the counts in front of its first chunk up
+    // directly (64 loads per thread at most); beyond, group sums come first.
+    const u64* groupSum = nullptr;
+    if (chunkBound > (ws.groupSumsFrom > 0 ? ws.groupSumsFrom : 16384)) {
+        const long long groups = chunkBound / kChunkGroup + 1;
+        hipLaunchKernelGGL(k_group_sums, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, s, ws.ffCount, ws.result,
+                           ws.groupSum);
+        groupSum = ws.groupSum;
+    }
+    if (bo) {
+        hipLaunchKernelGGL(k_image_ff_start, dim3((unsigned)(g.batch + 1)), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
+                           ws.ffCount, groupSum, ws.result, bo->ffStart);
+        hipLaunchKernelGGL(k_copy_headers, dim3((unsigned)g.batch), dim3(256), 0, s, *bo);
+        hipLaunchKernelGGL(k_stuff_bytes<true>, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
+                           ws.ffCount, groupSum, ws.result, bo->out, 0, 0, *bo, nullptr);
+    } else {
+        BatchOutput none = {};
+        hipLaunchKernelGGL(k_stuff_bytes<false>, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
+                           ws.ffCount, groupSum, ws.result, d_out, prefixLen, outCapacity, none, ws.hostResult);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_entropy(const KGeom& g, const int16_t* d_coef, const u32* d_tables, const EntropyWorkspace& ws,
+                          uint8_t* d_out, long long prefixLen, long long outCapacity, int writeEoi, hipStream_t s) {
+    (void)writeEoi;   // carried in g.writeEoi
+    return run_entropy_stage(g, d_coef, d_tables, ws, d_out, prefixLen, outCapacity, nullptr, s);
+}
+
+hipError_t launch_entropy_batch(const KGeom& g, const int16_t* d_coef, const u32* d_tables,
+                                const EntropyWorkspace& ws, const BatchOutput& bo, hipStream_t s) {
+    return run_entropy_stage(g, d_coef, d_tables, ws, nullptr, 0, 0, &bo, s);
+}
+
+}  // namespace jpeghip

@@ -98,8 +98,24 @@ void huffman_from_histogram(const uint64_t counts[256], uint8_t lengths[256], ui
     }
 }
 
+// A table the kernels and the DHT writer can work with: no code longer than 16 bits, no
+// code wider than its length, and lengths that satisfy the Kraft inequality (a prefix code
+// with these lengths exists).
+bool huffman_table_is_sane(const uint8_t lengths[256], const uint16_t codes[256]) {
+    uint64_t kraft = 0;   // in units of 2^-16
+    for (int s = 0; s < 256; ++s) {
+        const int len = lengths[s];
+        if (len == 0) continue;
+        if (len > 16) return false;
+        if (len < 16 && (codes[s] >> len) != 0) return false;
+        kraft += 1ull << (16 - len);
+    }
+    return kraft <= (1ull << 16);
+}
+
 int write_dht(const uint8_t lengths[256], const uint16_t codes[256], int tableId, int coefType, uint8_t* out,
               int capacity) {
+    if (!huffman_table_is_sane(lengths, codes)) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     // Symbols ordered by (length, code), JPEGSegments.h:117-129.
     int syms[256];
     int n = 0;
