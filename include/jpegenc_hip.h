@@ -124,6 +124,22 @@ int jpeg_hip_compute_layout(const jpeg_hip_params* params, jpeg_hip_layout* out_
 int jpeg_hip_encode(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
                     const jpeg_hip_params* params, uint8_t* d_out, int64_t out_capacity, int64_t* out_len);
 
+/* jpeg_hip_encode for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same arguments, same bytes written to d_out, but the device workspace
+ * (coefficients, histograms, tables, tile states, the unstuffed stream) is a fixed array of
+ * jpeg_hip_static_workspace_bytes() bytes (32 MiB) that is part of the library and that every
+ * GPU the library runs on holds until the process ends; the call makes no hipMalloc /
+ * hipFree.  Limits: 128 bytes per 8x8 block plus the entropy-coded stream of the image must
+ * fit the array (1920x1080 in any sampling scheme does); rows of byte pixels that do not
+ * start on 4-byte boundaries take a slower kernel instead of a realigned copy.  Larger
+ * images fail with JPEG_HIP_ERR_BUFFER_TOO_SMALL and a message.  All calls on one GPU, from
+ * any context, share that GPU's array: calls that overlap in time on one GPU race.  The
+ * context has to be re-begun (jpeg_hip_begin or a one-call entry point) before staged calls. */
+int jpeg_hip_encode_static(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
+                           const jpeg_hip_params* params, uint8_t* d_out, int64_t out_capacity, int64_t* out_len);
+int64_t jpeg_hip_static_workspace_bytes(void);
+
 /* Same with host buffers (copies in and out; PCIe time included). */
 int jpeg_hip_encode_host(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format, int64_t stride_bytes,
                          const jpeg_hip_params* params, uint8_t* h_out, int64_t out_capacity, int64_t* out_len);

@@ -177,23 +177,19 @@ void fill_kgeom(jpeg_hip_ctx* ctx) {
 // Workspace for `images` images of the current geometry (1 outside batch mode; in a batch
 // every image is one interval of the combined stream).
 int ensure_workspace(jpeg_hip_ctx* ctx, int images = 1) {
-    const Geometry& g = ctx->geo;
-    const int64_t nb = g.totalBlocks * images;
-    const int64_t intervals = images > 1 ? images : g.intervals;
-    // Entropy-coded bits plus the RSTn/EOI markers the bit writer places in the stream.
-    const int64_t unstuffedCap = (worst_case_scan_bytes(nb) + 2 * intervals + 2 + kStuffChunk + 63) / 16 * 16;
-    const int64_t maxChunks = (unstuffedCap + kStuffChunk - 1) / kStuffChunk;
-    HIP_TRY(ctx, ctx->coef.ensure((size_t)nb * 128));
-    HIP_TRY(ctx, ctx->qtab.ensure(sizeof ctx->pin->qtab));
-    HIP_TRY(ctx, ctx->hist.ensure(1024 * sizeof(uint64_t) * images));
-    HIP_TRY(ctx, ctx->tables.ensure(1024 * sizeof(uint32_t) * images + kHeaderCapacity));
-    HIP_TRY(ctx, ctx->ivOff.ensure((size_t)(intervals + 1) * 8));
-    HIP_TRY(ctx, ctx->ffCount.ensure((size_t)maxChunks * 4));
-    HIP_TRY(ctx, ctx->groupSum.ensure((size_t)(maxChunks / 64 + 2) * 8));
-    HIP_TRY(ctx, ctx->result.ensure(4 * 8));
-    HIP_TRY(ctx, ctx->unstuffed.ensure((size_t)unstuffedCap));
-    const int64_t tiles = (g.totalBlocks + 255) / 256 * images;
-    HIP_TRY(ctx, ctx->tileState.ensure((size_t)(tiles + 1) * 8));
+    // With borrowed buffers the unstuffed stream gets what its slice holds, not the worst case.
+    const WorkspaceSizes sz = workspace_sizes(ctx->geo, images, ctx->staticWorkspace ? (int64_t)ctx->unstuffed.cap : -1);
+    const int64_t unstuffedCap = sz.unstuffedCap, maxChunks = sz.maxChunks;
+    HIP_TRY(ctx, ctx->coef.ensure(sz.coef));
+    HIP_TRY(ctx, ctx->qtab.ensure(sz.qtab));
+    HIP_TRY(ctx, ctx->hist.ensure(sz.hist));
+    HIP_TRY(ctx, ctx->tables.ensure(sz.tables));
+    HIP_TRY(ctx, ctx->ivOff.ensure(sz.ivOff));
+    HIP_TRY(ctx, ctx->ffCount.ensure(sz.ffCount));
+    HIP_TRY(ctx, ctx->groupSum.ensure(sz.groupSum));
+    HIP_TRY(ctx, ctx->result.ensure(sz.result));
+    HIP_TRY(ctx, ctx->unstuffed.ensure(sz.unstuffed));
+    HIP_TRY(ctx, ctx->tileState.ensure(sz.tileState));
     EntropyWorkspace& ws = ctx->ws;
     ws.ivOff = (unsigned long long*)ctx->ivOff.p;
     ws.ffCount = (uint32_t*)ctx->ffCount.p;
@@ -327,6 +323,10 @@ int run_entropy_launch(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_
     // Padding (< 1 byte) and a marker per interval on top of the coded bits, EOI, slack.
     // Without histograms the output capacity bounds the stream: a longer one fails anyway.
     ctx->ws.streamBound = ctx->streamBits < 0 ? capacity - prefix : ctx->streamBits / 8 + 3 * ctx->geo.intervals + 2 + 64;
+    // A workspace of fixed size may hold less than the worst case: the stream has to fit.
+    if (ctx->ws.unstuffedCap < workspace_sizes(ctx->geo, 1).unstuffedCap &&
+        ctx->ws.streamBound + kStuffChunk + 64 > ctx->ws.unstuffedCap)
+        return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "the entropy-coded stream does not fit the workspace");
     // The kernels write length and error flags into the pinned record themselves.
     ctx->pin->result[0] = ctx->pin->result[1] = ctx->pin->result[2] = 0;
     ctx->ws.hostResult = (unsigned long long*)ctx->pin->result;
@@ -396,7 +396,9 @@ int do_transform(jpeg_hip_ctx* ctx, int stages, bool staged = false, uint64_t* c
     // 4-byte boundaries (an odd width, packed) are realigned by a copy kernel first, a
     // fraction of what the byte-wise kernel would cost.
     const void* rgb = ctx->rgb;
-    if (ctx->fmt == JPEG_HIP_RGB8 && stages == JPEG_HIP_STAGE_ALL && ctx->kg.nGains == 0 &&
+    // (Not with a borrowed workspace, which has no room for the copy: the byte-wise kernel
+    // takes such rows as they are.)
+    if (ctx->fmt == JPEG_HIP_RGB8 && stages == JPEG_HIP_STAGE_ALL && ctx->kg.nGains == 0 && !ctx->staticWorkspace &&
         ((ctx->stride & 3) != 0 || ((uintptr_t)rgb & 3) != 0)) {
         const int rows = std::min(band_rows_available(g), g.bandRows * g.stepH);
         int64_t dstStride = 0;
@@ -481,6 +483,7 @@ int jpeg_hip_create(int device_id, jpeg_hip_ctx** out_ctx) {
     if (device_id < 0 || device_id >= count) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     DeviceScope scope(device_id);
     if (scope.err != hipSuccess) return JPEG_HIP_ERR_HIP;
+    if (static_workspace_init(device_id) != hipSuccess) return JPEG_HIP_ERR_HIP;
     jpeg_hip_ctx* ctx = new (std::nothrow) jpeg_hip_ctx();
     if (!ctx) return JPEG_HIP_ERR_HIP;
     ctx->device = device_id;

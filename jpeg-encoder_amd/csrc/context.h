@@ -24,8 +24,10 @@ namespace jpeghip {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool borrowed = false;   // p is a slice of memory owned elsewhere: never freed, never grown
     hipError_t ensure(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
+        if (borrowed) return hipErrorOutOfMemory;
         if (p) {
             hipError_t e = hipFree(p);
             p = nullptr;
@@ -43,9 +45,10 @@ struct DevBuf {
         return hipSuccess;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !borrowed) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        borrowed = false;
     }
 };
 
@@ -156,6 +159,40 @@ private:
     bool stop_ = false;
 };
 
+// Bytes of every buffer of the device workspace for `images` images of geometry g (1 outside
+// batch mode; in a batch every image is one interval of the combined stream).
+// unstuffedLimit >= 0 caps the unstuffed stream below its worst case (a workspace of fixed
+// size); the caller then has to check the stream's real bound against unstuffedCap.
+struct WorkspaceSizes {
+    int64_t unstuffedCap, maxChunks, tiles;
+    size_t coef, qtab, hist, tables, ivOff, ffCount, groupSum, result, unstuffed, tileState;
+};
+
+inline WorkspaceSizes workspace_sizes(const Geometry& g, int images, int64_t unstuffedLimit = -1) {
+    WorkspaceSizes w;
+    const int64_t nb = g.totalBlocks * images;
+    const int64_t intervals = images > 1 ? images : g.intervals;
+    // Entropy-coded bits plus the RSTn/EOI markers the bit writer places in the stream.
+    w.unstuffedCap = (worst_case_scan_bytes(nb) + 2 * intervals + 2 + kStuffChunk + 63) / 16 * 16;
+    if (unstuffedLimit >= 0 && unstuffedLimit / 16 * 16 < w.unstuffedCap) w.unstuffedCap = unstuffedLimit / 16 * 16;
+    w.maxChunks = (w.unstuffedCap + kStuffChunk - 1) / kStuffChunk;
+    w.tiles = (g.totalBlocks + 255) / 256 * images;
+    w.coef = (size_t)nb * 128;
+    w.qtab = sizeof(Pinned::qtab);
+    w.hist = 1024 * sizeof(uint64_t) * (size_t)images;
+    w.tables = 1024 * sizeof(uint32_t) * (size_t)images + kHeaderCapacity;
+    w.ivOff = (size_t)(intervals + 1) * 8;
+    w.ffCount = (size_t)w.maxChunks * 4;
+    w.groupSum = (size_t)(w.maxChunks / 64 + 2) * 8;
+    w.result = 4 * 8;
+    w.unstuffed = (size_t)w.unstuffedCap;
+    w.tileState = (size_t)(w.tiles + 1) * 8;
+    return w;
+}
+
+// This GPU's copy of the static workspace array (static_workspace.hip); called with `device` current.
+hipError_t static_workspace_init(int device);
+
 constexpr int kBatchParts = 8;   // pieces a batch pass is cut into to hide the host's table building
 
 }  // namespace jpeghip
@@ -169,6 +206,7 @@ struct jpeg_hip_ctx {
     jpeghip::KGeom kg;
     bool begun = false, hasPixels = false, transformed = false, hasTables = false, qtabOnDevice = false;
     bool scanInFlight = false;                   // between jpeg_hip_finish_band_start and _wait
+    bool staticWorkspace = false;                // the workspace buffers are borrowed slices of fixed size: nothing may be allocated
     int64_t stagedScanLen = -1;   // scan of the current coefficients and tables held in `staging`, or -1
     int64_t streamBits = -1;      // entropy-coded bits the installed tables spend on the histograms they came from, or -1
     const void* rgb = nullptr;

@@ -20,7 +20,7 @@ DC, AC = 0, 1
 
 EXPORTS = [
     "jpeg_hip_create", "jpeg_hip_destroy", "jpeg_hip_last_error", "jpeg_hip_status_string", "jpeg_hip_stream",
-    "jpeg_hip_compute_layout", "jpeg_hip_encode", "jpeg_hip_encode_host", "jpeg_hip_encode_batch", "jpeg_hip_encode_batch_host", "jpeg_hip_begin", "jpeg_hip_upload_pixels", "jpeg_hip_upload_planes",
+    "jpeg_hip_compute_layout", "jpeg_hip_encode", "jpeg_hip_encode_static", "jpeg_hip_static_workspace_bytes", "jpeg_hip_encode_host", "jpeg_hip_encode_batch", "jpeg_hip_encode_batch_host", "jpeg_hip_begin", "jpeg_hip_upload_pixels", "jpeg_hip_upload_planes",
     "jpeg_hip_bind_pixels", "jpeg_hip_transform", "jpeg_hip_histograms", "jpeg_hip_histograms_host",
     "jpeg_hip_huffman_from_histogram", "jpeg_hip_standard_huffman", "jpeg_hip_write_dht", "jpeg_hip_write_headers", "jpeg_hip_set_huffman",
     "jpeg_hip_build_huffman", "jpeg_hip_get_huffman", "jpeg_hip_emit_scan", "jpeg_hip_emit_scan_host",
@@ -86,6 +86,9 @@ def lib():
         L.jpeg_hip_compute_layout.argtypes = [C.POINTER(Params), C.POINTER(Layout)]
         L.jpeg_hip_encode.argtypes = [vp, vp, i32, i64, C.POINTER(Params), vp, i64, C.POINTER(i64)]
         L.jpeg_hip_encode_host.argtypes = [vp, vp, i32, i64, C.POINTER(Params), vp, i64, C.POINTER(i64)]
+        L.jpeg_hip_encode_static.argtypes = [vp, vp, i32, i64, C.POINTER(Params), vp, i64, C.POINTER(i64)]
+        L.jpeg_hip_static_workspace_bytes.argtypes = []
+        L.jpeg_hip_static_workspace_bytes.restype = i64
         L.jpeg_hip_encode_batch.argtypes = [vp, vp, i32, i64, i64, i32, C.POINTER(Params), vp, i64, vp]
         L.jpeg_hip_encode_batch_host.argtypes = [vp, vp, i32, i64, i64, i32, C.POINTER(Params), vp, i64, vp]
         L.jpeg_hip_begin.argtypes = [vp, C.POINTER(Params)]
@@ -245,6 +248,13 @@ class Context:
         n = C.c_int64(0)
         self._check(lib().jpeg_hip_encode(self._h, C.c_void_p(d_rgb), fmt, stride, C.byref(params), C.c_void_p(d_out),
                                           capacity, C.byref(n)))
+        return n.value
+
+    def encode_static(self, d_rgb, fmt, stride, params, d_out, capacity):
+        """jpeg_hip_encode on the library's fixed workspace: allocates no device memory."""
+        n = C.c_int64(0)
+        self._check(lib().jpeg_hip_encode_static(self._h, C.c_void_p(d_rgb), fmt, stride, C.byref(params),
+                                                 C.c_void_p(d_out), capacity, C.byref(n)))
         return n.value
 
     def encode_batch(self, d_rgb, fmt, stride, image_stride, count, params, d_out, slot_bytes):
