@@ -304,11 +304,38 @@ int build_tables(jpeg_hip_ctx* ctx, const uint64_t* hist, bool stageHeader = fal
 // Runs the entropy kernels and reads the length back.  prefix: bytes already placed at
 // the start of d_out (headers).
 // Launches the entropy kernels; run_entropy_wait collects their result.
+// Tile size of the bit writer on groups for a mean block length (bits), 0: the one-lane-per-block
+// writer.  A tile's bits are staged in 28 Kibit of LDS; a tile that does not fit is reported by
+// the kernel and the stage is run again one size down (16 blocks fit whatever they hold).
+int group_tile_for(int64_t avgBlockBits) {
+    if (avgBlockBits < 0 || avgBlockBits <= 64) return 256;
+    if (avgBlockBits <= 256) return 64;
+    return 0;
+}
+
+int launch_entropy_kernels(jpeg_hip_ctx* ctx) {
+    // Padding (< 1 byte) and a marker per interval on top of the coded bits, EOI, slack.
+    // Without histograms the output capacity bounds the stream: a longer one fails anyway.
+    const int64_t prefix = ctx->emitPrefix, capacity = ctx->emitCapacity;
+    ctx->ws.streamBound = ctx->streamBits < 0 ? capacity - prefix : ctx->streamBits / 8 + 3 * ctx->geo.intervals + 2 + 64;
+    // A workspace of fixed size may hold less than the worst case: the stream has to fit.
+    if (ctx->ws.unstuffedCap < workspace_sizes(ctx->geo, 1).unstuffedCap &&
+        ctx->ws.streamBound + kStuffChunk + 64 > ctx->ws.unstuffedCap)
+        return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "the entropy-coded stream does not fit the workspace");
+    // The kernels write length and error flags into the pinned record themselves.
+    ctx->pin->result[0] = ctx->pin->result[1] = ctx->pin->result[2] = ctx->pin->result[3] = 0;
+    ctx->ws.hostResult = (unsigned long long*)ctx->pin->result;
+    HIP_TRY(ctx, launch_entropy(ctx->kg, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, ctx->emitOut,
+                                prefix, capacity, ctx->kg.writeEoi, ctx->stream));
+    return JPEG_HIP_OK;
+}
+
 int run_entropy_launch(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_t capacity, int writeEoi) {
     mark(ctx, 3);
     ctx->kg.writeEoi = writeEoi;
     // The histograms (and so streamBits) cover the whole image even when this context encodes a band.
     ctx->ws.avgBlockBits = ctx->streamBits < 0 ? -1 : ctx->streamBits / ((int64_t)ctx->geo.mcuRows * ctx->geo.mcusPerRow * ctx->geo.blocksPerMcu);
+    ctx->ws.groupTile = group_tile_for(ctx->ws.avgBlockBits);
     ctx->ws.header = (const uint8_t*)ctx->tables.p + sizeof ctx->pin->tables;
     ctx->ws.headerLen = (int)prefix;
     // A header staged with the tables is fetched with them; a launch without header (a
@@ -320,20 +347,12 @@ int run_entropy_launch(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_
         ctx->ws.pendingTables = nullptr;
     }
     ctx->tablesPending = false;
-    // Padding (< 1 byte) and a marker per interval on top of the coded bits, EOI, slack.
-    // Without histograms the output capacity bounds the stream: a longer one fails anyway.
-    ctx->ws.streamBound = ctx->streamBits < 0 ? capacity - prefix : ctx->streamBits / 8 + 3 * ctx->geo.intervals + 2 + 64;
-    // A workspace of fixed size may hold less than the worst case: the stream has to fit.
-    if (ctx->ws.unstuffedCap < workspace_sizes(ctx->geo, 1).unstuffedCap &&
-        ctx->ws.streamBound + kStuffChunk + 64 > ctx->ws.unstuffedCap)
-        return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "the entropy-coded stream does not fit the workspace");
-    // The kernels write length and error flags into the pinned record themselves.
-    ctx->pin->result[0] = ctx->pin->result[1] = ctx->pin->result[2] = 0;
-    ctx->ws.hostResult = (unsigned long long*)ctx->pin->result;
-    HIP_TRY(ctx, launch_entropy(ctx->kg, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, d_out,
-                                prefix, capacity, writeEoi, ctx->stream));
+    ctx->emitOut = d_out;
+    ctx->emitPrefix = prefix;
+    ctx->emitCapacity = capacity;
+    const int st = launch_entropy_kernels(ctx);
     mark(ctx, 4);
-    return JPEG_HIP_OK;
+    return st;
 }
 
 int run_entropy_wait(jpeg_hip_ctx* ctx, int64_t* outLen) {
@@ -344,7 +363,21 @@ int run_entropy_wait(jpeg_hip_ctx* ctx, int64_t* outLen) {
         if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->times[1] = ms;
         if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->times[2] = ms;
     }
-    if (ctx->pin->result[2] != 0) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer's tiles lost their chain");
+    // What the bit writer reports beside its bytes: 2 the chain of tiles broke, 4 the stream ran
+    // past the part of the buffer that was cleared for it, 8 a tile's bits did not fit its
+    // stage, 16 a symbol occurred that the tables have no code for.  4 and 8 are cured by running
+    // the stage again with a full clear / with smaller tiles.
+    for (int attempt = 0; attempt < 4 && (ctx->pin->result[3] & (4 | 8)) != 0 && (ctx->pin->result[3] & (2 | 16)) == 0; ++attempt) {
+        if (ctx->pin->result[3] & 4) ctx->streamBits = -1;
+        if (ctx->pin->result[3] & 8) ctx->ws.groupTile = ctx->ws.groupTile > 64 ? 64 : (ctx->ws.groupTile > 16 ? 16 : 0);
+        ctx->ws.pendingTables = nullptr;   // tables and header are on the device by now
+        const int st = launch_entropy_kernels(ctx);
+        if (st != JPEG_HIP_OK) return st;
+        HIP_TRY(ctx, wait_stream(ctx));
+    }
+    if (ctx->pin->result[3] & 16) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "the Huffman tables have no code for a symbol of this image");
+    if (ctx->pin->result[3] & (4 | 8)) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer could not place its stream");
+    if (ctx->pin->result[2] != 0 || (ctx->pin->result[3] & 2)) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer's tiles lost their chain");
     if (ctx->pin->result[1] != 0) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "output buffer is too small for the scan");
     *outLen = (int64_t)ctx->pin->result[0];
     return JPEG_HIP_OK;
@@ -1188,14 +1221,23 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     // Without histograms the slots bound the stream: a longer one fails anyway.
     ctx->ws.streamBound = totalBits < 0 ? (int64_t)n * slotBytes : totalBits / 8 + 3 * (int64_t)n + 2 + 64;
     ctx->ws.avgBlockBits = totalBits < 0 ? -1 : totalBits / ((int64_t)n * g.totalBlocks);
+    ctx->ws.groupTile = group_tile_for(ctx->ws.avgBlockBits);
     mark(ctx, 3);
-    HIP_TRY(ctx, launch_entropy_batch(k, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, bo, ctx->stream));
-    mark(ctx, 4);
     uint64_t* off = (uint64_t*)ctx->hostOffsets.p;   // [n+1] stream offsets, [n+1] stuffing offsets, [4] result
-    HIP_TRY(ctx, hipMemcpyAsync(off, ctx->ivOff.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(off + n + 1, ctx->batchFfStart.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(off + 2 * (n + 1), ctx->result.p, 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, wait_stream(ctx));
+    for (int attempt = 0;; ++attempt) {
+        HIP_TRY(ctx, launch_entropy_batch(k, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, bo, ctx->stream));
+        if (attempt == 0) mark(ctx, 4);
+        HIP_TRY(ctx, hipMemcpyAsync(off, ctx->ivOff.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(off + n + 1, ctx->batchFfStart.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(off + 2 * (n + 1), ctx->result.p, 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, wait_stream(ctx));
+        // Flags of the bit writer as in run_entropy_wait: a stage that was too small (8) or a
+        // stream beyond the cleared bytes (4) are cured by a second run.
+        const uint64_t flags = off[2 * (n + 1) + 1];
+        if ((flags & (4 | 8)) == 0 || (flags & (2 | 16)) != 0 || attempt == 3) break;
+        if (flags & 4) ctx->ws.streamBound = -1;
+        if (flags & 8) ctx->ws.groupTile = ctx->ws.groupTile > 64 ? 64 : (ctx->ws.groupTile > 16 ? 16 : 0);
+    }
     if (ctx->profiling) {
         float ms = 0;
         if (standard) {
@@ -1209,7 +1251,9 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
         if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->times[2] += ms;
     }
     if (off[2 * (n + 1) + 1] & 2) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer's tiles lost their chain");
-    bool overflow = off[2 * (n + 1) + 1] != 0;
+    if (off[2 * (n + 1) + 1] & 16) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "the Huffman tables have no code for a symbol of an image");
+    if (off[2 * (n + 1) + 1] & (4 | 8)) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer could not place its stream");
+    bool overflow = (off[2 * (n + 1) + 1] & 1) != 0;
     const uint32_t* hdrLen = (const uint32_t*)ctx->hostHdrLen.p;
     for (int i = 0; i < n; ++i) {
         lens[i] = (int64_t)hdrLen[i] + (int64_t)(off[i + 1] - off[i]) + (int64_t)(off[n + 1 + i + 1] - off[n + 1 + i]);

@@ -176,7 +176,8 @@ inline WorkspaceSizes workspace_sizes(const Geometry& g, int images, int64_t uns
     w.unstuffedCap = (worst_case_scan_bytes(nb) + 2 * intervals + 2 + kStuffChunk + 63) / 16 * 16;
     if (unstuffedLimit >= 0 && unstuffedLimit / 16 * 16 < w.unstuffedCap) w.unstuffedCap = unstuffedLimit / 16 * 16;
     w.maxChunks = (w.unstuffedCap + kStuffChunk - 1) / kStuffChunk;
-    w.tiles = (g.totalBlocks + 255) / 256 * images;
+    // One state word per tile of the bit writer; its smallest tiles are 16 blocks, in fours per image.
+    w.tiles = ((g.totalBlocks + 15) / 16 + 4) * images;
     w.coef = (size_t)nb * 128;
     w.qtab = sizeof(Pinned::qtab);
     w.hist = 1024 * sizeof(uint64_t) * (size_t)images;
@@ -208,6 +209,8 @@ struct jpeg_hip_ctx {
     bool scanInFlight = false;                   // between jpeg_hip_finish_band_start and _wait
     bool staticWorkspace = false;                // the workspace buffers are borrowed slices of fixed size: nothing may be allocated
     int64_t stagedScanLen = -1;   // scan of the current coefficients and tables held in `staging`, or -1
+    uint8_t* emitOut = nullptr;                  // arguments of the entropy stage in flight, for a second run
+    int64_t emitPrefix = 0, emitCapacity = 0;
     int64_t streamBits = -1;      // entropy-coded bits the installed tables spend on the histograms they came from, or -1
     const void* rgb = nullptr;
     int fmt = JPEG_HIP_RGB8;

@@ -1,5 +1,7 @@
 // Entropy stage of the MI355X (gfx950) JPEG encode hot path: symbol histograms, the
 // single-pass bit writer and byte stuffing.
+#include <cstdlib>
+
 #include "device_common.h"
 #include "kernels.h"
 
@@ -122,6 +124,12 @@ __device__ __forceinline__ void load_block(const int16_t* coef, long long b, u32
 
 constexpr int kEntThreads = 256;
 
+// Diagnostic switch: JPEGENC_OLD_ENTROPY=1 selects the one-lane-per-block kernels throughout.
+static bool old_entropy_kernels() {
+    static const bool old = getenv("JPEGENC_OLD_ENTROPY") != nullptr && getenv("JPEGENC_OLD_ENTROPY")[0] == '1';
+    return old;
+}
+
 // ---- histograms -------------------------------------------------------------------------
 struct HistVisitor {
     u32* dcHist;
@@ -202,6 +210,8 @@ hipError_t launch_clear_histograms(unsigned long long* d_hist, int images, hipSt
     return hipGetLastError();
 }
 
+__global__ void k_histogram_groups(KGeom g, const int16_t* __restrict__ coef, u64* __restrict__ hist, HistogramExport ex);
+
 hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, bool clear,
                             HistogramExport* ex) {
     if (clear) {
@@ -219,6 +229,19 @@ hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, 
     long long grid = (passes + rounds - 1) / rounds;
     if (grid < 1) grid = 1;
     HistogramExport none = {nullptr, 0, nullptr};
+    if (!old_entropy_kernels()) {
+        // Four tiles of 256 blocks per workgroup and round; workgroups are cheap here (3 KiB of counters to flush).
+        const long long tiles = (g.blocksPerImage + 255) / 256;
+        long long want = (tiles + 3) / 4;
+        const long long most = g.batch > 1 ? (8192 / g.batch > 8 ? 8192 / g.batch : 8) : 4096;
+        const long long rnds = (want + most - 1) / most;
+        grid = (want + rnds - 1) / rnds;
+        if (grid < 1) grid = 1;
+        if (ex != nullptr && g.batch == 1) ex->expected += (unsigned long long)grid;
+        hipLaunchKernelGGL(k_histogram_groups, dim3((unsigned)grid, (unsigned)g.batch), dim3(256), 0, s, g, d_coef, d_hist,
+                           ex != nullptr && g.batch == 1 ? *ex : none);
+        return hipGetLastError();
+    }
     if (ex != nullptr && g.batch == 1) ex->expected += (unsigned long long)grid;   // what the counter reads when all are done
     hipLaunchKernelGGL(k_histogram, dim3((unsigned)grid, (unsigned)g.batch), dim3(kEntThreads), 0, s, g, d_coef, d_hist,
                        ex != nullptr && g.batch == 1 ? *ex : none);
@@ -482,6 +505,12 @@ __device__ __forceinline__ bool look_back(const u64* state, long long tile, u64 
     }
 }
 
+#include "entropy_groups.h"
+
+static long long group_tiles_per_image(long long blocksPerImage, int tileBlocks) {
+    return ((blocksPerImage + tileBlocks - 1) / tileBlocks + 3) / 4 * 4;
+}
+
 // kPrivate: blocks are short on average (photographic content), so the first walk keeps
 // each block's bits in a few private LDS words and the second walk is a copy; otherwise the
 // first walk only measures and every block is walked twice.
@@ -588,7 +617,7 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
         if (lane == 0) {
             if (!ok) {
                 start = p0;
-                result[1] = 2;
+                atomicOr((unsigned long long*)&result[1], 2ull);
                 if (hostResult) hostResult[2] = 2;
             }
             __hip_atomic_store(state + tile, kTilePosition | pos_apply(whole, start), __ATOMIC_RELAXED,
@@ -864,7 +893,7 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
         if (onePiece) {
             if (base + (long long)total > limit) {
                 if (threadIdx.x == 0) {
-                    result[1] = 1;
+                    atomicOr((unsigned long long*)&result[1], 1ull);
                     if (hostResult) hostResult[1] = 1;
                 }
             } else {
@@ -914,11 +943,14 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
                 }
                 ff += extra;
             }
-            if (overflow) result[1] = 1;
+            if (overflow) atomicOr((unsigned long long*)&result[1], 1ull);
         }
         if (!kBatch && ch == chunks - 1 && threadIdx.x == 0) {
             result[0] = (u64)(base + (long long)total);
-            if (hostResult) hostResult[0] = (u64)(base + (long long)total);
+            if (hostResult) {
+                hostResult[0] = (u64)(base + (long long)total);
+                hostResult[3] = result[1] & ~1ull;   // what the bit writer flagged (it has finished)
+            }
         }
         const u64 chunkBytes = bytes - (u64)c0 < (u64)kStuffChunk ? bytes - (u64)c0 : (u64)kStuffChunk;
         ffBefore += total - chunkBytes;   // what the chunk wrote beyond its own bytes
@@ -986,7 +1018,12 @@ __global__ __launch_bounds__(256) void k_prepare_entropy(uint4* __restrict__ str
 static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const u32* d_tables,
                                     const EntropyWorkspace& ws, uint8_t* d_out, long long prefixLen,
                                     long long outCapacity, const BatchOutput* bo, hipStream_t s) {
-    const long long tilesPerImage = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
+    // Bit writer on groups (tiles of ws.groupTile blocks, one per wave) unless the restart
+    // intervals are shorter than it takes, or the diagnostic switch asks for the other one.
+    const bool groups = ws.groupTile > 0 && !old_entropy_kernels() &&
+                        (g.intervals == g.batch || g.mcusPerInterval * g.bpm >= kGrpMinIntervalBlocks);
+    const long long tilesPerImage = groups ? group_tiles_per_image(g.blocksPerImage, ws.groupTile)
+                                           : (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
     const long long tileCount = tilesPerImage * g.batch;
     // The bit writer ORs into the stream, so the part it can reach starts out as zeros.
     long long zero = ws.streamBound < 0 ? ws.unstuffedCap : (ws.streamBound + kStuffChunk + 63) / 16 * 16;
@@ -1001,7 +1038,10 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
                        bo ? nullptr : ws.pendingTables, const_cast<u32*>(d_tables));
     // Long blocks (noise, q=100) do not fit the private words; unknown lengths count as short.
     const bool shortBlocks = ws.avgBlockBits <= 128;
-    if (shortBlocks)
+    if (groups)
+        hipLaunchKernelGGL(k_encode_groups, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, d_coef, d_tables, ws.tileState,
+                           ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero);
+    else if (shortBlocks)
         hipLaunchKernelGGL(k_encode_bits<true>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
                            ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult);
     else

@@ -69,6 +69,7 @@ struct EntropyWorkspace {
     unsigned long long* tileState;   // [tiles + 1] of the single-pass bit writer (tiles of 256 blocks)
     long long streamBound;           // upper bound of the unstuffed stream in bytes, or < 0 when unknown
     long long avgBlockBits;          // mean entropy-coded bits per block according to the histograms, or < 0 when unknown
+    int groupTile;                   // blocks per tile of the bit writer on groups: 256, 64 or 16; 0: the one-lane-per-block writer
     const uint8_t* header;           // file header staged in device memory, copied to the front of the output
     int headerLen;                   // (0: none); prefixLen of launch_entropy covers it
     // Tables (uint32[4][256]) and, right behind them, headerLen header bytes in pinned host

@@ -223,14 +223,22 @@ def test_staged_table_sequences(ctx):
     ctx.build_huffman(ctx.histograms())
     assert emit() == ea.scan
     assert emit() == ea.scan                       # second emit: the device copy of the tables
-    # image a under image b's tables, then back under its own
-    ctx.set_huffman(eb.lengths, eb.codes)
-    O.set_fixed_tables(eb.lengths, eb.codes)
+    # image a under tables that are not its own (the Annex K ones have a code for every symbol),
+    # then back under its own
+    std_lengths, std_codes = B.standard_huffman()
+    ctx.set_huffman(std_lengths, std_codes)
+    O.set_fixed_tables(std_lengths, std_codes)
     try:
-        a_under_b = O.encode(a, T.SCHEME_420, qt).scan
+        a_under_std = O.encode(a, T.SCHEME_420, qt).scan
     finally:
         O.set_fixed_tables()
-    assert emit() == a_under_b
+    assert emit() == a_under_std
+    # image b's tables lack symbols that image a has: an error, not a stream with holes
+    assert ((ea.hist > 0) & (eb.lengths == 0)).any()
+    ctx.set_huffman(eb.lengths, eb.codes)
+    with pytest.raises(B.JpegHipError) as err:
+        emit()
+    assert err.value.status == B.ERR_INVALID_ARGUMENT
     ctx.set_huffman(ea.lengths, ea.codes)
     assert emit() == ea.scan
     # a whole-file encode of b installs b's tables and header; a staged emit afterwards uses them
