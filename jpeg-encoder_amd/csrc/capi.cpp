@@ -172,6 +172,7 @@ void fill_kgeom(jpeg_hip_ctx* ctx) {
     k.imageStrideBytes = 0;
     k.tableStride = 1024;
     k.nGains = 0;
+    k.groupMask = (const unsigned char*)ctx->gmask.p;
 }
 
 // Workspace for `images` images of the current geometry (1 outside batch mode; in a batch
@@ -181,6 +182,7 @@ int ensure_workspace(jpeg_hip_ctx* ctx, int images = 1) {
     const WorkspaceSizes sz = workspace_sizes(ctx->geo, images, ctx->staticWorkspace ? (int64_t)ctx->unstuffed.cap : -1);
     const int64_t unstuffedCap = sz.unstuffedCap, maxChunks = sz.maxChunks;
     HIP_TRY(ctx, ctx->coef.ensure(sz.coef));
+    HIP_TRY(ctx, ctx->gmask.ensure(sz.gmask));
     HIP_TRY(ctx, ctx->qtab.ensure(sz.qtab));
     HIP_TRY(ctx, ctx->hist.ensure(sz.hist));
     HIP_TRY(ctx, ctx->tables.ensure(sz.tables));
@@ -308,6 +310,7 @@ int build_tables(jpeg_hip_ctx* ctx, const uint64_t* hist, bool stageHeader = fal
 // writer.  A tile's bits are staged in 28 Kibit of LDS; a tile that does not fit is reported by
 // the kernel and the stage is run again one size down (16 blocks fit whatever they hold).
 int group_tile_for(int64_t avgBlockBits) {
+    if (const char* forced = getenv("JPEGENC_GROUP_TILE")) return atoi(forced);   // diagnostic switch: 256, 64, 16 or 0
     if (avgBlockBits < 0 || avgBlockBits <= 64) return 256;
     if (avgBlockBits <= 256) return 64;
     return 0;
@@ -441,8 +444,8 @@ int do_transform(jpeg_hip_ctx* ctx, int stages, bool staged = false, uint64_t* c
         ctx->kg.strideBytes = (long long)dstStride;
     }
     mark(ctx, 0);
-    HIP_TRY(ctx, launch_transform(ctx->kg, rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, ctx->stream,
-                                  (unsigned long long*)clearHist));
+    HIP_TRY(ctx, launch_transform(ctx->kg, rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, (unsigned char*)ctx->gmask.p,
+                                  ctx->stream, (unsigned long long*)clearHist));
     mark(ctx, 1);
     ctx->transformed = true;
     ctx->stagedScanLen = -1;
@@ -538,7 +541,7 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     if (!ctx) return;
     DeviceScope scope(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->groupSum, &ctx->result,
+    DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->gmask, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->groupSum, &ctx->result,
                       &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart,
                       &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum, &ctx->pixelsF, &ctx->pipeIn[0], &ctx->pipeIn[1],
                       &ctx->pipeOut, &ctx->histDone, &ctx->gather, &ctx->repacked};
@@ -1095,7 +1098,8 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     if (standard) {
         // One table set and one header serve every image; nothing waits for the host.
         mark(ctx, 0);
-        HIP_TRY(ctx, launch_transform(k, d_rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, ctx->stream));
+        HIP_TRY(ctx, launch_transform(k, d_rgb, (const float*)ctx->qtab.p, (int16_t*)ctx->coef.p, (unsigned char*)ctx->gmask.p,
+                                      ctx->stream));
         mark(ctx, 1);
         mark(ctx, 2);
         k.tableStride = 0;
@@ -1135,6 +1139,7 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
         kp.intervals = cnt;
         kp.nMcu = g.nMcu * cnt;
         kp.totalBlocks = g.totalBlocks * cnt;
+        kp.groupMask = (const unsigned char*)ctx->gmask.p + (int64_t)a * g.totalBlocks;
         return kp;
     };
     for (int grp = 0; grp < groups; ++grp) {
@@ -1148,7 +1153,8 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
             HIP_TRY(ctx, hipEventRecord(ctx->groupTime[grp][0], ctx->stream));
         }
         HIP_TRY(ctx, launch_transform(part_geometry(ga, gcnt), d_rgb + (int64_t)ga * imageStride, (const float*)ctx->qtab.p,
-                                      (int16_t*)ctx->coef.p + (int64_t)ga * g.totalBlocks * 64, ctx->stream));
+                                      (int16_t*)ctx->coef.p + (int64_t)ga * g.totalBlocks * 64,
+                                      (unsigned char*)ctx->gmask.p + (int64_t)ga * g.totalBlocks, ctx->stream));
         if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->groupTime[grp][1], ctx->stream));
         for (int p = p0; p < p1; ++p) {
             const int a = partBegin[p], cnt = partBegin[p + 1] - a;

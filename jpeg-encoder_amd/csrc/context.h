@@ -165,7 +165,7 @@ private:
 // size); the caller then has to check the stream's real bound against unstuffedCap.
 struct WorkspaceSizes {
     int64_t unstuffedCap, maxChunks, tiles;
-    size_t coef, qtab, hist, tables, ivOff, ffCount, groupSum, result, unstuffed, tileState;
+    size_t coef, gmask, qtab, hist, tables, ivOff, ffCount, groupSum, result, unstuffed, tileState;
 };
 
 inline WorkspaceSizes workspace_sizes(const Geometry& g, int images, int64_t unstuffedLimit = -1) {
@@ -179,6 +179,7 @@ inline WorkspaceSizes workspace_sizes(const Geometry& g, int images, int64_t uns
     // One state word per tile of the bit writer; its smallest tiles are 16 blocks, in fours per image.
     w.tiles = ((g.totalBlocks + 15) / 16 + 4) * images;
     w.coef = (size_t)nb * 128;
+    w.gmask = (size_t)nb + 64;   // one byte per block, read in dwords
     w.qtab = sizeof(Pinned::qtab);
     w.hist = 1024 * sizeof(uint64_t) * (size_t)images;
     w.tables = 1024 * sizeof(uint32_t) * (size_t)images + kHeaderCapacity;
@@ -216,7 +217,7 @@ struct jpeg_hip_ctx {
     int fmt = JPEG_HIP_RGB8;
     int64_t stride = 0;
     jpeghip::DevBuf repacked;                             // byte pixels whose rows did not start on 4-byte boundaries, rows realigned
-    jpeghip::DevBuf pixels, coef, qtab, hist, tables, ivOff, ffCount, groupSum, result, unstuffed,
+    jpeghip::DevBuf pixels, coef, gmask, qtab, hist, tables, ivOff, ffCount, groupSum, result, unstuffed,
         staging, batchHdr, batchHdrLen, batchFfStart, tileState, decCoef, decPlanes, decTables, decRgb, decSum, pixelsF, pipeIn[2], pipeOut;
     jpeghip::DecodedStream* decoded = nullptr;   // last file given to the verification decoder
     jpeghip::WorkerPool* workers = nullptr;               // created by the first batch pass

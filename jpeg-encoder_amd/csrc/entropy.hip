@@ -123,6 +123,7 @@ __device__ __forceinline__ void load_block(const int16_t* coef, long long b, u32
 }
 
 constexpr int kEntThreads = 256;
+constexpr u32 kNoCodeLength = 0x4000u;   // stands in for the length of a symbol without a code (a block has at most 64 * 27 bits)
 
 // Diagnostic switch: JPEGENC_OLD_ENTROPY=1 selects the one-lane-per-block kernels throughout.
 static bool old_entropy_kernels() {
@@ -210,8 +211,6 @@ hipError_t launch_clear_histograms(unsigned long long* d_hist, int images, hipSt
     return hipGetLastError();
 }
 
-__global__ void k_histogram_groups(KGeom g, const int16_t* __restrict__ coef, u64* __restrict__ hist, HistogramExport ex);
-
 hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, bool clear,
                             HistogramExport* ex) {
     if (clear) {
@@ -229,19 +228,6 @@ hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, 
     long long grid = (passes + rounds - 1) / rounds;
     if (grid < 1) grid = 1;
     HistogramExport none = {nullptr, 0, nullptr};
-    if (!old_entropy_kernels()) {
-        // Four tiles of 256 blocks per workgroup and round; workgroups are cheap here (3 KiB of counters to flush).
-        const long long tiles = (g.blocksPerImage + 255) / 256;
-        long long want = (tiles + 3) / 4;
-        const long long most = g.batch > 1 ? (8192 / g.batch > 8 ? 8192 / g.batch : 8) : 4096;
-        const long long rnds = (want + most - 1) / most;
-        grid = (want + rnds - 1) / rnds;
-        if (grid < 1) grid = 1;
-        if (ex != nullptr && g.batch == 1) ex->expected += (unsigned long long)grid;
-        hipLaunchKernelGGL(k_histogram_groups, dim3((unsigned)grid, (unsigned)g.batch), dim3(256), 0, s, g, d_coef, d_hist,
-                           ex != nullptr && g.batch == 1 ? *ex : none);
-        return hipGetLastError();
-    }
     if (ex != nullptr && g.batch == 1) ex->expected += (unsigned long long)grid;   // what the counter reads when all are done
     hipLaunchKernelGGL(k_histogram, dim3((unsigned)grid, (unsigned)g.batch), dim3(kEntThreads), 0, s, g, d_coef, d_hist,
                        ex != nullptr && g.batch == 1 ? *ex : none);
@@ -518,7 +504,8 @@ template <bool kPrivate>
 __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int16_t* __restrict__ coef,
                                                              const u32* __restrict__ tables, u64* __restrict__ state,
                                                              u64* __restrict__ ivOff, u64* __restrict__ result,
-                                                             u32* __restrict__ words, u64* __restrict__ hostResult) {
+                                                             u32* __restrict__ words, u64* __restrict__ hostResult,
+                                                             long long zeroedBytes) {
     __shared__ u32 tab[4 * 256];
     constexpr int kStageWords = kPrivate ? kEmitStageShort : kEmitStageLong;
     __shared__ u32 stage[kStageWords];
@@ -550,7 +537,12 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
         fetchedDc = coef[dc_predictor_source(role, b) * 64];
     }
     const u32* myTables = tables + image * g.tableStride;
-    for (int i = threadIdx.x; i < 1024; i += kEntThreads) tab[i] = myTables[i];
+    // A symbol the tables have no code for (length 0) gets a length no block can reach, so
+    // that a block which uses one shows in its bit count.
+    for (int i = threadIdx.x; i < 1024; i += kEntThreads) {
+        const u32 e = myTables[i];
+        tab[i] = (e >> 16) == 0 ? kNoCodeLength << 16 : e;
+    }
     __syncthreads();
 
     long long iv = 0;
@@ -575,6 +567,10 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
             LengthVisitor len{tab + 256 * t, tab + 512 + 256 * t, 0u};
             walk_block(w, pred, len);
             bits = len.bits;
+        }
+        if (bits >= kNoCodeLength) {   // report it and write nothing for the block
+            atomicOr((unsigned long long*)&result[1], 16ull);
+            bits = 0;
         }
         mine.x = bits;
         if (lastOfInterval) {
@@ -655,6 +651,8 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
                 ivOff[g.intervals] = bytes;
                 result[2] = bytes;
                 result[3] = (bytes + kStuffChunk - 1) / kStuffChunk;
+                // The stream was ORed into a buffer cleared up to zeroedBytes: beyond, it is garbage.
+                if ((long long)bytes > zeroedBytes) atomicOr((unsigned long long*)&result[1], 4ull);
             }
         }
         if (threadIdx.x == 0) span[0] = begin;
@@ -673,7 +671,9 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
         const BitTarget out{staged ? stage : words, staged ? (long long)wordBase : 0, !staged};
         const u64 start = pos + (leadMarker ? 16 : 0);   // first bit of the block itself
         if (leadMarker) out.or32(pos, leadMarker << 16);
-        if (kPrivate && bits <= (u32)(kPrivWords * 32)) {
+        if (bits == 0) {
+            // a block with a symbol that has no code: flagged above
+        } else if (kPrivate && bits <= (u32)(kPrivWords * 32)) {
             const u32* mine32 = priv + threadIdx.x * kPrivPitch;
 #pragma unroll
             for (int k = 0; k < kPrivWords; ++k)
@@ -1020,7 +1020,12 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
                                     long long outCapacity, const BatchOutput* bo, hipStream_t s) {
     // Bit writer on groups (tiles of ws.groupTile blocks, one per wave) unless the restart
     // intervals are shorter than it takes, or the diagnostic switch asks for the other one.
-    const bool groups = ws.groupTile > 0 && !old_entropy_kernels() &&
+    // It pays from a few hundred thousand blocks on; below, a wave's walk through a whole tile
+    // is a longer chain than the image has work to hide (1080p: 37 -> 44 us).
+    // (Diagnostic switch JPEGENC_GROUP_MIN_BLOCKS: another threshold, e.g. 0 to test it on small images.)
+    const char* minEnv = getenv("JPEGENC_GROUP_MIN_BLOCKS");
+    const long long minBlocks = minEnv ? atoll(minEnv) : kGrpMinBlocks;
+    const bool groups = ws.groupTile > 0 && !old_entropy_kernels() && g.totalBlocks >= minBlocks &&
                         (g.intervals == g.batch || g.mcusPerInterval * g.bpm >= kGrpMinIntervalBlocks);
     const long long tilesPerImage = groups ? group_tiles_per_image(g.blocksPerImage, ws.groupTile)
                                            : (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
@@ -1043,10 +1048,10 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
                            ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero);
     else if (shortBlocks)
         hipLaunchKernelGGL(k_encode_bits<true>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
-                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult);
+                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult, zero);
     else
         hipLaunchKernelGGL(k_encode_bits<false>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
-                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult);
+                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult, zero);
     long long chunkGrid = chunkBound < 4096 ? chunkBound : 4096;
     if (chunkGrid < 1) chunkGrid = 1;
     long long countGrid = (chunkBound + 3) / 4;

@@ -3,11 +3,14 @@
 // A block's 64 zig-zag ordered coefficients are eight groups of eight (16 bytes each).  After
 // quantization most groups of a photographic image are all zero (three of eight survive at
 // q=90), and an all-zero group codes nothing: its zeros only lengthen the run in front of
-// the next non-zero coefficient.  The kernels here therefore work on the groups that are
-// not empty.  A wave reads rows of 64 groups (8 blocks x 8 groups, lane l: block l / 8,
-// group l % 8 -- one fully coalesced 1 KiB read), keeps the non-empty ones in scan order in a
-// small ring in LDS (ballot + lane count give every group its slot), and whenever 64 of them
-// have come together one lane takes one group: eight coefficients, no loop, no divergence.
+// the next non-zero coefficient.  The transform leaves one byte per block that says which
+// groups are not empty; the kernels here read those bytes, list the non-empty groups of a
+// tile in scan order (a prefix sum over the bytes' bit counts gives every group its place), and
+// then one lane takes one group: a 16-byte read of eight coefficients, no loop over them, no
+// divergence, and the empty groups are never read at all.
+// (A histogram pass built the same way was measured as well: 231 us for the 16384 x 16384 image
+// against the 201 us of k_histogram, whose one-lane-per-block walk skips empty groups for a
+// whole wave at once and has no list to build; it was dropped.)
 // Zero runs come from bit masks (the eight non-zero flags of the group, one sentinel bit for
 // the zeros that earlier groups of the block left behind) and v_ffbh, categories from the
 // exponent of the value converted to float (Encoder::lookupBitCategory, Encoder.cpp:354-366),
@@ -16,11 +19,14 @@
 //
 // Every wave of a workgroup works on a tile of its own; the waves share the tables only.
 
-constexpr int kGrpQueue = 256;                   // ring capacity in groups (a power of two)
+constexpr int kGrpTileBlocks = 256;              // largest tile, blocks (four per lane)
+constexpr int kGrpMaxItems = kGrpTileBlocks * 9; // eight groups and an interval end per block
 constexpr int kGrpStageWords = 896;              // stage of one wave's tile, words (four workgroups fit a CU's LDS)
 constexpr int kGrpStageBits = kGrpStageWords * 32;
 constexpr int kGrpMaxFix = 24;                   // interval ends a tile can hold (intervals are >= 16 blocks)
 constexpr int kGrpMinIntervalBlocks = 16;
+constexpr long long kGrpMinBlocks = 200000;       // images (or batches) below this many blocks keep the one-lane-per-block writer
+constexpr u32 kGrpBaseBlocks = 32;               // the tile's base address lies this many blocks in front of its first block
 
 // Symbol tables in LDS, one word per (table, run, category): rows of 16 categories, 23 rows
 // per AC table (a run of 16..22 in front of a group's first coefficient aliases run & 15),
@@ -35,17 +41,19 @@ constexpr int kTabWords = kTabZrl + 2;
 // 31..27.  Symbols of category 0 inside the AC rows stand for zero coefficients: empty.
 constexpr u32 kTokAbsent = 0xF8000000u;          // the table has no code for a symbol (31 is no length)
 
-// Queue tags: [15:0] DC predictor (group 0 only), [18:16] group, [26:19] block inside the
-// tile, [27] chroma, [28] not a group but the end of a restart interval.
-constexpr u32 kTagPseudo = 1u << 28, kTagChroma = 1u << 27;
-constexpr u32 kTagKeyMask = (0xffu << 19) | kTagPseudo;
+// An item of a tile's list: (block inside the tile << 4) | group; group 8 stands for the end
+// of a restart interval behind the block's last group.
+constexpr u32 kItemNone = 0xffffu;
 
-__device__ __forceinline__ u32 lanes_below(u64 mask) {
-    return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+// min(a, b) on both 16-bit halves (the compiler turns the vector form into compares and selects).
+__device__ __forceinline__ u32 pk_min_u16(u32 a, u32 b) {
+    u32 r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
-__device__ __forceinline__ u32 dpp_or_zero(u32 v, int ctrl, int rowMask) {
-    // lanes without a source lane (or outside rowMask) get 0
+__device__ __forceinline__ u32 dpp_or_zero(u32 v, int ctrl) {
+    // lanes without a source lane (or outside the row mask) get 0
     switch (ctrl) {
         case 0x111: return __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);
         case 0x112: return __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);
@@ -58,128 +66,146 @@ __device__ __forceinline__ u32 dpp_or_zero(u32 v, int ctrl, int rowMask) {
 
 // Inclusive sum over the 64 lanes of a wave (row shifts, then the two row broadcasts).
 __device__ __forceinline__ u32 wave_scan_add(u32 v) {
-    v += dpp_or_zero(v, 0x111, 0xf);
-    v += dpp_or_zero(v, 0x112, 0xf);
-    v += dpp_or_zero(v, 0x114, 0xf);
-    v += dpp_or_zero(v, 0x118, 0xf);
-    v += dpp_or_zero(v, 0x142, 0xa);
-    v += dpp_or_zero(v, 0x143, 0xc);
+    v += dpp_or_zero(v, 0x111);
+    v += dpp_or_zero(v, 0x112);
+    v += dpp_or_zero(v, 0x114);
+    v += dpp_or_zero(v, 0x118);
+    v += dpp_or_zero(v, 0x142);
+    v += dpp_or_zero(v, 0x143);
     return v;
 }
 
-// Per block of a tile: bit 0 chroma, bit 1 the DC predictor restarts at 0, bits 6..2 distance
-// to the previous block of the channel, bit 7 last block of a restart interval.
-__device__ __forceinline__ u32 group_block_role(const KGeom& g, u32 bl) {
-    const BlockRole r = block_role(g, bl);
-    bool last = bl == (u32)g.blocksPerImage - 1;
-    if (g.intervals != g.batch && r.k == g.bpm - 1 && (r.mcu + 1) % (u32)g.mcusPerInterval == 0) last = true;
-    return (r.c != 0 ? 1u : 0u) | (r.resets ? 2u : 0u) | ((u32)r.back << 2) | (last ? 0x80u : 0u);
-}
-
-// One wave's view of its tile and its ring.
+// One wave's view of its tile.
 struct GroupTile {
-    const int16_t* image;    // coefficients of the tile's image
+    const char* base;        // address of the tile's first block minus kGrpBaseBlocks blocks: predictors lie in front
+    const unsigned char* mask;   // group masks of the tile's blocks
     u32 first;               // first block of the tile inside its image
     int nBlocks;
-    uint4* qData;
-    u32* qTag;
-    unsigned char* role;
+    unsigned short* items;   // [kGrpMaxItems + 2]
+    unsigned char* role;     // [kGrpTileBlocks]
+    int nItems;
 };
 
-struct GroupRows {
-    uint4 d[2];
-    int pred[2];
-    u32 role[2];
-};
-
-// Reads rows 2 * it and 2 * it + 1 of the tile (16 blocks): every lane one group per row, group 0
-// lanes also the DC term their block is predicted from.
-__device__ __forceinline__ void group_load_rows(const GroupTile& t, int it, GroupRows& rows) {
-    const int lane = threadIdx.x & 63, k = lane & 7;
+// Lists the tile's non-empty groups in scan order and notes every block's role: bit 0 chroma,
+// bit 1 the DC predictor restarts at 0, bits 6..2 distance to the previous block of the
+// channel, bit 7 last block of a restart interval (kIntervals only; such a block gets an
+// item of its own behind its groups).  Lane l looks after blocks 4l..4l+3.
+template <bool kIntervals>
+__device__ __forceinline__ void group_index_tile(const KGeom& g, GroupTile& t) {
+    const int lane = threadIdx.x & 63;
+    const int lb0 = 4 * lane;
+    // Position of the lane's first block: two divisions, the other three blocks follow by counting.
+    const u32 bpm = (u32)g.bpm;
+    const u32 bl0 = t.first + (u32)lb0;
+    u32 mcu = bl0 / bpm;
+    int k = (int)(bl0 - mcu * bpm);
+    const bool oneInterval = g.intervals == g.batch;   // no restarts, or a batch: the image is the interval
+    u32 inInterval = oneInterval ? mcu : mcu % (u32)g.mcusPerInterval;
+    const u32 lastInInterval = oneInterval ? ~0u : (u32)g.mcusPerInterval - 1;
+    u32 counts = 0, total = 0;
+    u32 masks[4];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int lb = it * 16 + r * 8 + (lane >> 3);
+    for (int i = 0; i < 4; ++i) {
+        const int lb = lb0 + i;
         const bool valid = lb < t.nBlocks;
-        rows.d[r] = make_uint4(0, 0, 0, 0);
-        rows.pred[r] = 0;
-        rows.role[r] = 0;
-        if (valid) {
-            const u32 role = t.role[lb];
-            rows.role[r] = role;
-            const long long b = (long long)t.first + lb;
-            rows.d[r] = *(const uint4*)(t.image + b * 64 + k * 8);
-            if (k == 0) rows.pred[r] = t.image[(b - ((role & 2u) ? 0 : (long long)((role >> 2) & 31u))) * 64];
+        const int c = k < g.off1 ? 0 : (k < g.off2 ? 1 : 2);
+        const int first = c == 0 ? 0 : (c == 1 ? g.off1 : g.off2);
+        const int end = c == 0 ? g.off1 : (c == 1 ? g.off2 : g.bpm);
+        const u32 back = k > first ? 1u : (u32)(g.bpm - (end - 1 - first));
+        const bool last = kIntervals && (t.first + (u32)lb == (u32)g.blocksPerImage - 1 ||
+                                         (inInterval == lastInInterval && k == g.bpm - 1));
+        const u32 role = (c != 0 ? 1u : 0u) | (k == first && inInterval == 0 ? 2u : 0u) | (back << 2) | (last ? 0x80u : 0u);
+        if (valid) t.role[lb] = (unsigned char)role;
+        const u32 m = valid ? ((u32)t.mask[lb] | 1u | (last ? 0x100u : 0u)) : 0u;   // group 0 always: it carries the DC term
+        masks[i] = m;
+        counts |= total << (8 * i);   // items of the lane's earlier blocks (at most 27)
+        total += (u32)__popc(m);
+        if (++k == (int)bpm) {
+            k = 0;
+            ++mcu;
+            if (oneInterval) inInterval = mcu;
+            else if (++inInterval == (u32)g.mcusPerInterval) inInterval = 0;
         }
+    }
+    const u32 incl = wave_scan_add(total);
+    const u32 base = incl - total;
+    t.nItems = (int)__builtin_amdgcn_readlane(incl, 63);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32 slot = base + ((counts >> (8 * i)) & 0xffu);
+        const u32 m = masks[i];
+        const u32 item = (u32)(lb0 + i) << 4;
+#pragma unroll
+        for (int grp = 0; grp < (kIntervals ? 9 : 8); ++grp) {
+            if ((m >> grp) & 1u) t.items[slot] = (unsigned short)(item | (u32)grp);
+            slot += (m >> grp) & 1u;
+        }
+    }
+    if (lane == 0) {   // nothing follows the last item
+        t.items[t.nItems] = (unsigned short)kItemNone;
+        t.items[t.nItems + 1] = (unsigned short)kItemNone;
     }
 }
 
-// Appends the non-empty groups of two rows to the ring (in scan order) and, behind the last
-// group of a block that ends a restart interval, an entry for the interval's end.  Returns the
-// new tail.
-template <bool kIntervals>
-__device__ __forceinline__ u32 group_enqueue(const GroupTile& t, int it, const GroupRows& rows, u32 tail) {
-    const int lane = threadIdx.x & 63, k = lane & 7;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int lb = it * 16 + r * 8 + (lane >> 3);
-        const bool valid = lb < t.nBlocks;
-        const uint4 d = rows.d[r];
-        const bool nonempty = valid && (k == 0 || (d.x | d.y | d.z | d.w) != 0);
-        const u64 mN = __ballot(nonempty);
-        u32 pos = tail + lanes_below(mN);
-        u32 added = (u32)__popcll(mN);
-        if (kIntervals) {
-            const bool bnd = valid && k == 7 && (rows.role[r] & 0x80u) != 0;
-            const u64 mB = __ballot(bnd);
-            if (mB != 0) {
-                pos += lanes_below(mB);
-                added += (u32)__popcll(mB);
-                if (bnd) t.qTag[(pos + (nonempty ? 1u : 0u)) & (kGrpQueue - 1)] = kTagPseudo | ((u32)lb << 19) | (7u << 16);
-            }
-        }
-        if (nonempty) {
-            const u32 slot = pos & (kGrpQueue - 1);
-            const u32 pred = (rows.role[r] & 2u) ? 0u : ((u32)rows.pred[r] & 0xffffu);
-            t.qData[slot] = d;
-            t.qTag[slot] = (k == 0 ? pred : 0u) | ((u32)k << 16) | ((u32)lb << 19) | ((rows.role[r] & 1u) ? kTagChroma : 0u);
-        }
-        tail += added;
-    }
-    return tail;
+// The loads one lane issues for its item: the group's 16 bytes, and the DC term the block is
+// predicted from (used by group 0 only).
+struct GroupLoad {
+    uint4 d;
+    u32 pred;
+};
+
+__device__ __forceinline__ void group_issue_loads(const GroupTile& t, int firstItem, GroupLoad& ld) {
+    const int lane = threadIdx.x & 63;
+    int i = firstItem + lane;
+    i = i < t.nItems ? i : t.nItems - 1;    // idle lanes read what the last item reads
+    const u32 item = t.items[i];
+    const u32 lb = item >> 4, grp = item & 7u;
+    const u32 role = t.role[lb];
+    const u32 back = (role & 2u) ? 0u : ((role >> 2) & 31u);
+    ld.d = *(const uint4*)(t.base + ((lb + kGrpBaseBlocks) * 128u + grp * 16u));
+    ld.pred = *(const unsigned short*)(t.base + (lb + kGrpBaseBlocks - back) * 128u);
 }
 
 // What a lane knows about its group before it looks at single coefficients.
 struct GroupFront {
     u32 d[4];        // the eight coefficients (group 0: the DC term replaced by its difference)
-    u32 tag;
+    u32 lb;          // block inside the tile
     u32 mm;          // bits 7..0: coefficient j is not zero (group 0: bit 0 always set)
     u32 X;           // the same flags in bits 23..16 and a sentinel bit below them, see group_front
-    u32 val;         // (block key << 6) | index of the group's last non-zero coefficient
-    int k;
+    u32 val;         // (block << 6) | index of the group's last non-zero coefficient
     int zr;          // ZRL symbols in front of the group's first non-zero coefficient
     bool real;       // a group (not an interval end, not an idle lane)
+    bool boundary;   // an interval end
     bool isK0;
     bool needEob;
+    u32 chroma;      // 0 / 1
     u32 tabBase;     // byte offset of the group's AC rows in the table
 };
 
 // carryVal: `val` of the item in front of the chunk (wave uniform).
-__device__ __forceinline__ void group_front(const GroupTile& t, u32 head, int n, u32 carryVal, GroupFront& f) {
-    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void group_front(const GroupTile& t, int firstItem, const GroupLoad& ld, u32 carryVal,
+                                            GroupFront& f) {
     const int lane = threadIdx.x & 63;
-    const bool act = lane < n;
-    const u32 slot = (head + (u32)lane) & (kGrpQueue - 1);
-    const u32 tag = act ? t.qTag[slot] : kTagPseudo;
-    const u32 next = t.qTag[(slot + 1) & (kGrpQueue - 1)];
-    const bool pseudo = (tag & kTagPseudo) != 0;
-    f.real = !pseudo;
-    f.tag = tag;
-    uint4 q = t.qData[slot];
-    if (pseudo) q = make_uint4(0, 0, 0, 0);
-    f.k = (int)((tag >> 16) & 7u);
-    f.isK0 = f.real && f.k == 0;
-    if (f.isK0) {   // Encoder.cpp:268-272: the DC term is coded as the difference to its predecessor
-        const int diff = (int)(short)(q.x & 0xffffu) - (int)(short)(tag & 0xffffu);
+    const int i = firstItem + lane;
+    const bool act = i < t.nItems;
+    const int ic = act ? i : t.nItems - 1;
+    const u32 item = t.items[ic];
+    const u32 next = t.items[ic + 1];
+    const u32 grp = item & 15u;
+    f.lb = item >> 4;
+    f.boundary = act && grp == 8u;
+    f.real = act && grp != 8u;
+    const u32 role = t.role[f.lb];
+    f.chroma = role & 1u;
+    f.isK0 = f.real && grp == 0u;
+    uint4 q = ld.d;
+    q.x = f.real ? q.x : 0u;
+    q.y = f.real ? q.y : 0u;
+    q.z = f.real ? q.z : 0u;
+    q.w = f.real ? q.w : 0u;
+    if (f.isK0) {   // Encoder.cpp:268-272: the DC term is coded as the difference to its predecessor (0 where a new interval starts)
+        const int pred = (role & 2u) ? 0 : (int)(short)ld.pred;
+        const int diff = (int)(short)(q.x & 0xffffu) - pred;
         q.x = (q.x & 0xffff0000u) | ((u32)diff & 0xffffu);
     }
     f.d[0] = q.x; f.d[1] = q.y; f.d[2] = q.z; f.d[3] = q.w;
@@ -187,28 +213,25 @@ __device__ __forceinline__ void group_front(const GroupTile& t, u32 head, int n,
     // dwords interleave to even bits 0..6 (even coefficients) and 16..22 (odd ones).
     u32 a = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const us2 one = {1, 1};
-        const us2 nz = __builtin_elementwise_min(__builtin_bit_cast(us2, f.d[i]), one);
-        a |= __builtin_bit_cast(u32, nz) << (2 * i);
-    }
+    for (int w = 0; w < 4; ++w) a |= pk_min_u16(f.d[w], 0x00010001u) << (2 * w);
     u32 mm = a | (a >> 15);           // bits 7..0 in coefficient order (bits 16..22 are left-overs)
     if (f.isK0) mm |= 1u;             // runs are counted from the DC term whatever its difference is
     f.mm = mm;
     const int tz = (int)__builtin_clz((mm << 24) | 0x00800000u);   // zero coefficients at the group's end, 0..8
-    const u32 key = (tag >> 19) & 0x3ffu;
-    f.val = (key << 6) | (u32)(f.k * 8 + 7 - tz);
+    f.val = (f.lb << 6) | (u32)((int)(grp & 7u) * 8 + 7 - tz);
     const u32 prev = __builtin_amdgcn_update_dpp(carryVal, f.val, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    // Zero coefficients between the block's last non-zero one and this group (0 for group 0).
-    const int carry = (f.real && (prev >> 6) == key) ? f.k * 8 - 1 - (int)(prev & 63u) : 0;
+    // Zero coefficients between the block's last non-zero one and this group (0 for group 0:
+    // the item in front of it belongs to another block).
+    const int carry = (f.real && (prev >> 6) == f.lb) ? (int)grp * 8 - 1 - (int)(prev & 63u) : 0;
     // clz(X << (16 - j)) is the zero run in front of coefficient j: flags above, the sentinel
     // (carry & 15) + 1 places below the group's first flag.
     f.X = (mm << 16) | (1u << (15 - (carry & 15)));
     const int firstNz = (int)__builtin_ctz(mm | 0x100u);
     f.zr = f.real ? (firstNz + carry) >> 4 : 0;
-    const bool lastOfBlock = ((tag ^ next) & kTagKeyMask) != 0;
-    f.needEob = f.real && lastOfBlock && !(f.k == 7 && (mm & 0x80u));   // Encoder.cpp:343-347
-    f.tabBase = (tag & kTagChroma) ? kTabAcWords * 4u : 0u;
+    // Last group of its block: the next item belongs to another block, or is the interval's end.
+    const bool lastOfBlock = (next >> 4) != f.lb || (next & 15u) == 8u;
+    f.needEob = f.real && lastOfBlock && !(grp == 7u && (mm & 0x80u));   // Encoder.cpp:343-347
+    f.tabBase = f.chroma * (kTabAcWords * 4u);
 }
 
 // Byte offset of coefficient j's symbol in the table: AC row `run`, column `category`; the DC
@@ -218,99 +241,8 @@ __device__ __forceinline__ u32 group_symbol_offset(const GroupFront& f, int j, i
     cat = __builtin_amdgcn_frexp_expf((float)v);   // bits of |v|, 0 for 0
     const u32 run = (u32)__builtin_clz(f.X << (16 - j));
     u32 off = f.tabBase + (run << 6) + ((u32)cat << 2);
-    if (j == 0 && f.isK0) off = kTabDc * 4u + ((f.tag & kTagChroma) ? 64u : 0u) + ((u32)cat << 2);
+    if (j == 0 && f.isK0) off = kTabDc * 4u + f.chroma * 64u + ((u32)cat << 2);
     return off;
-}
-
-// ---- histograms ---------------------------------------------------------------------------
-// Counters in LDS laid out like the symbol table; the bins of category 0 inside the AC rows
-// collect the zero coefficients and are dropped.
-__global__ __launch_bounds__(256) void k_histogram_groups(KGeom g, const int16_t* __restrict__ coef,
-                                                          u64* __restrict__ hist, HistogramExport ex) {
-    __shared__ u32 lh[kTabWords];
-    __shared__ __attribute__((aligned(16))) uint4 qData[4][kGrpQueue];
-    __shared__ u32 qTag[4][kGrpQueue];
-    __shared__ unsigned char roleTab[4][256];
-    __shared__ bool lastOne;
-    for (int i = threadIdx.x; i < kTabWords; i += 256) lh[i] = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    GroupTile t;
-    t.image = coef + (long long)blockIdx.y * g.blocksPerImage * 64;
-    t.qData = qData[wave];
-    t.qTag = qTag[wave];
-    t.role = roleTab[wave];
-    const u32 blocks = (u32)g.blocksPerImage;
-    const u32 tiles = (blocks + 255) / 256;
-    for (u32 tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
-        t.first = tile * 256;
-        t.nBlocks = (int)(blocks - t.first < 256u ? blocks - t.first : 256u);
-        for (int lb = lane; lb < t.nBlocks; lb += 64) t.role[lb] = (unsigned char)group_block_role(g, t.first + lb);
-        u32 head = 0, tail = 0, carryVal = ~0u;
-        const int iters = (t.nBlocks + 15) / 16;
-        GroupRows cur, nxt;
-        group_load_rows(t, 0, cur);
-        for (int it = 0; it <= iters; ++it) {
-            if (it < iters) {
-                if (it + 1 < iters) group_load_rows(t, it + 1, nxt);
-                tail = __builtin_amdgcn_readfirstlane(group_enqueue<false>(t, it, cur, tail));
-                if (lane == 0) t.qTag[tail & (kGrpQueue - 1)] = ~0u;   // nothing follows the last item yet
-                cur = nxt;
-            }
-            // A full chunk needs the tag of the item behind it (end-of-block test); the last
-            // chunks take what is left.
-            while (tail - head >= 65 || (it == iters && tail != head)) {
-                const int n = tail - head < 64 ? (int)(tail - head) : 64;
-                GroupFront f;
-                group_front(t, head, n, carryVal, f);
-                carryVal = __builtin_amdgcn_readlane(f.val, n - 1);
-                head += (u32)n;
-                if (f.real) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        int cat;
-                        const u32 off = group_symbol_offset(f, j, cat);
-                        atomicAdd(&lh[off >> 2], 1u);
-                    }
-                    const u32 c = (f.tag & kTagChroma) ? 1u : 0u;
-                    if (f.needEob) atomicAdd(&lh[kTabEob + c], 1u);
-                    if (f.zr != 0) atomicAdd(&lh[kTabZrl + c], (u32)f.zr);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // Counter i of the LDS layout -> bin of the histogram set (DC-Y, DC-C, AC-Y, AC-C), or none.
-    auto bin_of = [](int i) -> int {
-        if (i < kTabDc) {
-            const int c = i / kTabAcWords, rem = i - c * kTabAcWords, cat = rem & 15;
-            return cat == 0 ? -1 : (2 + c) * 256 + ((((rem >> 4) & 15) << 4) | cat);
-        }
-        if (i < kTabEob) return ((i - kTabDc) >> 4) * 256 + ((i - kTabDc) & 15);
-        if (i < kTabZrl) return (2 + (i - kTabEob)) * 256;
-        return (2 + (i - kTabZrl)) * 256 + 0xF0;
-    };
-    u64* mine = hist + (long long)blockIdx.y * 1024;
-    // The additions return their old values so that they have been performed when the
-    // workgroup counts itself off (see k_histogram).
-    u64 seen = 0;
-    for (int i = threadIdx.x; i < kTabWords; i += 256) {
-        const u32 v = lh[i];
-        const int bin = bin_of(i);
-        if (v != 0 && bin >= 0) {
-            if (ex.host != nullptr) seen |= atomicAdd(&mine[bin], (u64)v);
-            else atomicAdd(&mine[bin], (u64)v);
-        }
-    }
-    if (ex.host == nullptr) return;
-    if (seen == ~0ull) lh[0] = 0;
-    __syncthreads();
-    if (threadIdx.x == 0) lastOne = atomicAdd(ex.counter, 1ull) + 1 == ex.expected;
-    __syncthreads();
-    if (!lastOne) return;
-    for (int i = threadIdx.x; i < 1024; i += 256)
-        ex.host[i] = __hip_atomic_load(&hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- bit writer -----------------------------------------------------------------------------
@@ -351,10 +283,9 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
                                                        u64* __restrict__ ivOff, u64* __restrict__ result,
                                                        u32* __restrict__ words, int tileBlocks, long long zeroedBytes) {
     __shared__ u32 tab[kTabWords];
-    __shared__ __attribute__((aligned(16))) uint4 qData[4][kGrpQueue];
-    __shared__ u32 qTag[4][kGrpQueue];
+    __shared__ unsigned short items[4][kGrpMaxItems + 2];
+    __shared__ unsigned char roleTab[4][kGrpTileBlocks];
     __shared__ u32 stage[4][kGrpStageWords];
-    __shared__ unsigned char roleTab[4][256];
     __shared__ u32 fixBlock[4][kGrpMaxFix], fixRel[4][kGrpMaxFix];
     __shared__ unsigned long long ticket;
     const int lane = threadIdx.x & 63;
@@ -393,9 +324,7 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
     // wait for a tile of another wave of the same workgroup).
 
     GroupTile t;
-    t.image = coef + (long long)image * g.blocksPerImage * 64;
-    t.qData = qData[wave];
-    t.qTag = qTag[wave];
+    t.items = items[wave];
     t.role = roleTab[wave];
     u32* st = stage[wave];
     const u32 tileInImage = tile - image * tilesPerImage;
@@ -405,7 +334,10 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
         const long long left = g.blocksPerImage - (long long)t.first;
         t.nBlocks = (int)(left < tileBlocks ? left : tileBlocks);
     }
-    for (int lb = lane; lb < t.nBlocks; lb += 64) t.role[lb] = (unsigned char)group_block_role(g, t.first + lb);
+    t.base = (const char*)(coef + ((long long)image * g.blocksPerImage + t.first) * 64) - (long long)kGrpBaseBlocks * 128;
+    t.mask = g.groupMask + (long long)image * g.blocksPerImage + t.first;
+    t.nItems = 0;
+    if (t.nBlocks > 0) group_index_tile<true>(g, t);   // (a tile behind the image's last one is empty)
 
     // Position inside the tile's part of the stream, as a function of the position P at
     // which the tile starts: P + runX while no interval has ended inside the tile, after that
@@ -413,149 +345,145 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
     // staged from bit 0, the rest from a word boundary behind them, and the two pieces go to the
     // stream separately once P is known.
     u32 runX = 0, runY = 0;
-    u32 head = 0, tail = 0, carryVal = ~0u, nFix = 0;
+    u32 carryVal = ~0u, nFix = 0;
     u32 maxTok = 0;
     bool overflow = false;
-    const int iters = (t.nBlocks + 15) / 16;
-    GroupRows cur, nxt;
-    group_load_rows(t, 0, cur);
-    for (int it = 0; it <= iters; ++it) {
-        if (it < iters) {
-            if (it + 1 < iters) group_load_rows(t, it + 1, nxt);
-            tail = __builtin_amdgcn_readfirstlane(group_enqueue<true>(t, it, cur, tail));
-            if (lane == 0) t.qTag[tail & (kGrpQueue - 1)] = ~0u;
-            cur = nxt;
+    GroupLoad ld;
+    if (t.nItems > 0) group_issue_loads(t, 0, ld);
+    for (int first = 0; first < t.nItems; first += 64) {
+        GroupFront f;
+        group_front(t, first, ld, carryVal, f);
+        const int n = t.nItems - first < 64 ? t.nItems - first : 64;
+        carryVal = __builtin_amdgcn_readlane(f.val, n - 1);
+        group_issue_loads(t, first + 64, ld);   // the next chunk's groups arrive while this one is coded
+
+        // Tokens of the eight coefficients, with their bit counts.
+        typedef short s2 __attribute__((ext_vector_type(2)));
+        u32 amp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // v for v >= 0, v - 1 (the one's complement of |v|) for v < 0, Encoder.cpp:281-284
+            const s2 v = __builtin_bit_cast(s2, f.d[i]);
+            amp[i] = __builtin_bit_cast(u32, (s2)(v + (v >> 15)));
         }
-        while (tail - head >= 65 || (it == iters && tail != head)) {
-            const int n = tail - head < 64 ? (int)(tail - head) : 64;
-            GroupFront f;
-            group_front(t, head, n, carryVal, f);
-            carryVal = __builtin_amdgcn_readlane(f.val, n - 1);
-            head += (u32)n;
-            const bool boundary = lane < n && !f.real;
-
-            // Tokens of the eight coefficients, with their bit counts.
-            typedef short s2 __attribute__((ext_vector_type(2)));
-            u32 amp[4];
+        u32 tok[8], off[9];
+        const u32 zrlTok = tab[kTabZrl + f.chroma], eobTok = tab[kTabEob + f.chroma];
+        off[0] = (u32)f.zr * (zrlTok >> 27);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {   // v for v >= 0, v - 1 (the one's complement of |v|) for v < 0, Encoder.cpp:281-284
-                const s2 v = __builtin_bit_cast(s2, f.d[i]);
-                amp[i] = __builtin_bit_cast(u32, (s2)(v + (v >> 15)));
-            }
-            u32 tok[8], off[9];
-            const u32 c = (f.tag & kTagChroma) ? 1u : 0u;
-            const u32 zrlTok = tab[kTabZrl + c], eobTok = tab[kTabEob + c];
-            off[0] = (u32)f.zr * (zrlTok >> 27);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int cat;
-                const u32 o = group_symbol_offset(f, j, cat);
-                const u32 e = *(const u32*)((const char*)tab + o);
-                tok[j] = e | __builtin_amdgcn_ubfe(amp[j >> 1], 16 * (j & 1), (u32)cat);
-                maxTok = tok[j] > maxTok ? tok[j] : maxTok;
-                off[j + 1] = off[j] + (tok[j] >> 27);
-            }
-            if (f.zr != 0 && zrlTok > maxTok) maxTok = zrlTok;
-            if (f.needEob && eobTok > maxTok) maxTok = eobTok;
-            const u32 eobBits = f.needEob ? eobTok >> 27 : 0u;
-            const u32 len = f.real ? off[8] + eobBits : 0u;
+        for (int j = 0; j < 8; ++j) {
+            int cat;
+            const u32 o = group_symbol_offset(f, j, cat);
+            const u32 e = *(const u32*)((const char*)tab + o);
+            tok[j] = e | __builtin_amdgcn_ubfe(amp[j >> 1], 16 * (j & 1), (u32)cat);
+            off[j + 1] = off[j] + (tok[j] >> 27);
+        }
+        {   // a token of the "no code" kind is larger than any other
+            const u32 m0 = tok[0] > tok[1] ? tok[0] : tok[1], m1 = tok[2] > tok[3] ? tok[2] : tok[3];
+            const u32 m2 = tok[4] > tok[5] ? tok[4] : tok[5], m3 = tok[6] > tok[7] ? tok[6] : tok[7];
+            const u32 m01 = m0 > m1 ? m0 : m1, m23 = m2 > m3 ? m2 : m3;
+            const u32 m = m01 > m23 ? m01 : m23;
+            maxTok = m > maxTok ? m : maxTok;
+        }
+        if (f.zr != 0 && zrlTok > maxTok) maxTok = zrlTok;
+        if (f.needEob && eobTok > maxTok) maxTok = eobTok;
+        const u32 eobBits = f.needEob ? eobTok >> 27 : 0u;
+        const u32 len = f.real ? off[8] + eobBits : 0u;
 
-            // Where the lane's bits go in the stage.
-            u32 base;
-            if (__ballot(boundary) == 0) {
-                const u32 incl = wave_scan_add(len);
-                const u32 total = __builtin_amdgcn_readlane(incl, 63);
-                if ((runX >> 31) == 0) {
-                    base = runX + incl - len;
-                    runX += total;
-                } else {
-                    const u32 h = runX & 0x7fffffffu;
-                    base = ((h + 31u) & ~31u) + 32u + runY + incl - len;
-                    runY += total;
-                }
+        // Where the lane's bits go in the stage.
+        u32 base;
+        if (__ballot(f.boundary) == 0) {
+            const u32 incl = wave_scan_add(len);
+            const u32 total = __builtin_amdgcn_readlane(incl, 63);
+            if ((runX >> 31) == 0) {
+                base = runX + incl - len;
+                runX += total;
             } else {
-                // An interval ends inside the chunk: the general form of the scan.  The end pads
-                // the stream to a byte (BitBuffer::fillToByteBorder, BitBuffer.cpp:12-16) and
-                // is followed by EOI (the image ends) or the next interval's RSTn.
-                const u32 bl = t.first + ((f.tag >> 19) & 0xffu);
-                const bool lastBlock = bl == (u32)g.blocksPerImage - 1;
-                const u32 eoiBits = boundary && g.writeEoi && (g.batch > 1 || lastBlock) ? 16u : 0u;
-                const u32 rstBits = boundary && g.batch == 1 && !lastBlock ? 16u : 0u;
-                PosSummary mine = {len, 0u};
-                if (boundary) {
-                    mine.x = 0x80000000u;
-                    mine.y = eoiBits + rstBits;
-                }
-                PosSummary inc = mine;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    PosSummary o;
-                    o.x = __shfl_up(inc.x, d, 64);
-                    o.y = __shfl_up(inc.y, d, 64);
-                    if (lane >= d) inc = pos_combine(o, inc);
-                }
-                PosSummary excl;
-                excl.x = __shfl_up(inc.x, 1, 64);
-                excl.y = __shfl_up(inc.y, 1, 64);
-                if (lane == 0) excl.x = excl.y = 0;
-                const PosSummary run = {runX, runY};
-                const PosSummary at = pos_combine(run, excl);
-                const u32 h = at.x & 0x7fffffffu;
-                const u32 partB = ((h + 31u) & ~31u) + 32u;
-                base = (at.x >> 31) ? partB + at.y : at.x;
-                if (boundary) {
-                    // Offset, inside the part behind the tile's first interval end, at which this
-                    // end's padding stops.  The padding of the first end depends on P and is
-                    // left to the copy.
-                    u32 padded = 0;
-                    if (at.x >> 31) {
-                        padded = (at.y + 7u) & ~7u;
-                        if (g.padOnes && padded != at.y && partB + padded + 64u <= (u32)kGrpStageBits)
-                            stage_put(st, partB + at.y, (1u << (padded - at.y)) - 1u, padded - at.y);
-                    }
-                    const u32 iv = g.batch > 1 ? image : (bl / (u32)g.bpm) / (u32)g.mcusPerInterval;
-                    u32 marks = 0, nMarks = eoiBits + rstBits;
-                    if (eoiBits) marks = 0xffd9u;
-                    if (rstBits) marks = (marks << 16) | (0xffd0u + (u32)((g.firstInterval + iv) & 7));
-                    if (partB + padded + nMarks + 64u <= (u32)kGrpStageBits) {
-                        if (nMarks == 32u) {
-                            stage_put(st, partB + padded, marks >> 16, 16u);
-                            stage_put(st, partB + padded + 16u, marks & 0xffffu, 16u);
-                        } else if (nMarks != 0) {
-                            stage_put(st, partB + padded, marks, nMarks);
-                        }
-                    } else {
-                        overflow = true;
-                    }
-                    const u32 slot = nFix + lanes_below(__ballot(boundary));
-                    if (slot < (u32)kGrpMaxFix) {
-                        fixBlock[wave][slot] = bl;
-                        fixRel[wave][slot] = padded + eoiBits;
-                    } else {
-                        overflow = true;
-                    }
-                }
-                nFix += (u32)__popcll(__ballot(boundary));
-                const PosSummary whole = pos_combine(run, PosSummary{(u32)__builtin_amdgcn_readlane(inc.x, 63),
-                                                                     (u32)__builtin_amdgcn_readlane(inc.y, 63)});
-                runX = whole.x;
-                runY = whole.y;
+                const u32 h = runX & 0x7fffffffu;
+                base = ((h + 31u) & ~31u) + 32u + runY + incl - len;
+                runY += total;
             }
-            runX = __builtin_amdgcn_readfirstlane(runX);
-            runY = __builtin_amdgcn_readfirstlane(runY);
-
-            if (f.real) {
-                if (base + len + 64u <= (u32)kGrpStageBits) {
-                    if (f.zr != 0) {
-                        const u32 zl = zrlTok >> 27;
-                        for (int z = 0; z < f.zr; ++z) stage_put(st, base + (u32)z * zl, zrlTok & 0x07ffffffu, zl);
-                    }
+        } else {
+            // An interval ends inside the chunk: the general form of the scan.  The end pads
+            // the stream to a byte (BitBuffer::fillToByteBorder, BitBuffer.cpp:12-16) and
+            // is followed by EOI (the image ends) or the next interval's RSTn.
+            const u32 bl = t.first + f.lb;
+            const bool lastBlock = bl == (u32)g.blocksPerImage - 1;
+            const u32 eoiBits = f.boundary && g.writeEoi && (g.batch > 1 || lastBlock) ? 16u : 0u;
+            const u32 rstBits = f.boundary && g.batch == 1 && !lastBlock ? 16u : 0u;
+            PosSummary mine = {len, 0u};
+            if (f.boundary) {
+                mine.x = 0x80000000u;
+                mine.y = eoiBits + rstBits;
+            }
+            PosSummary inc = mine;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) stage_put(st, base + off[j], tok[j] & 0x07ffffffu, tok[j] >> 27);
-                    if (f.needEob) stage_put(st, base + off[8], eobTok & 0x07ffffffu, eobBits);
+            for (int d = 1; d < 64; d <<= 1) {
+                PosSummary o;
+                o.x = __shfl_up(inc.x, d, 64);
+                o.y = __shfl_up(inc.y, d, 64);
+                if (lane >= d) inc = pos_combine(o, inc);
+            }
+            PosSummary excl;
+            excl.x = __shfl_up(inc.x, 1, 64);
+            excl.y = __shfl_up(inc.y, 1, 64);
+            if (lane == 0) excl.x = excl.y = 0;
+            const PosSummary run = {runX, runY};
+            const PosSummary at = pos_combine(run, excl);
+            const u32 h = at.x & 0x7fffffffu;
+            const u32 partB = ((h + 31u) & ~31u) + 32u;
+            base = (at.x >> 31) ? partB + at.y : at.x;
+            const u64 ends = __ballot(f.boundary);
+            if (f.boundary) {
+                // Offset, inside the part behind the tile's first interval end, at which this
+                // end's padding stops.  The padding of the first end depends on P and is
+                // left to the copy.
+                u32 padded = 0;
+                if (at.x >> 31) {
+                    padded = (at.y + 7u) & ~7u;
+                    if (g.padOnes && padded != at.y && partB + padded + 64u <= (u32)kGrpStageBits)
+                        stage_put(st, partB + at.y, (1u << (padded - at.y)) - 1u, padded - at.y);
+                }
+                const u32 iv = g.batch > 1 ? image : (bl / (u32)g.bpm) / (u32)g.mcusPerInterval;
+                u32 marks = 0, nMarks = eoiBits + rstBits;
+                if (eoiBits) marks = 0xffd9u;
+                if (rstBits) marks = (marks << 16) | (0xffd0u + (u32)((g.firstInterval + iv) & 7));
+                if (partB + padded + nMarks + 64u <= (u32)kGrpStageBits) {
+                    if (nMarks == 32u) {
+                        stage_put(st, partB + padded, marks >> 16, 16u);
+                        stage_put(st, partB + padded + 16u, marks & 0xffffu, 16u);
+                    } else if (nMarks != 0) {
+                        stage_put(st, partB + padded, marks, nMarks);
+                    }
                 } else {
                     overflow = true;
                 }
+                const u32 slot = nFix + __builtin_amdgcn_mbcnt_hi((u32)(ends >> 32), __builtin_amdgcn_mbcnt_lo((u32)ends, 0u));
+                if (slot < (u32)kGrpMaxFix) {
+                    fixBlock[wave][slot] = bl;
+                    fixRel[wave][slot] = padded + eoiBits;
+                } else {
+                    overflow = true;
+                }
+            }
+            nFix += (u32)__popcll(ends);
+            const PosSummary whole = pos_combine(run, PosSummary{(u32)__builtin_amdgcn_readlane(inc.x, 63),
+                                                                 (u32)__builtin_amdgcn_readlane(inc.y, 63)});
+            runX = whole.x;
+            runY = whole.y;
+        }
+        runX = __builtin_amdgcn_readfirstlane(runX);
+        runY = __builtin_amdgcn_readfirstlane(runY);
+
+        if (f.real) {
+            if (base + len + 64u <= (u32)kGrpStageBits) {
+                if (f.zr != 0) {
+                    const u32 zl = zrlTok >> 27;
+                    for (int z = 0; z < f.zr; ++z) stage_put(st, base + (u32)z * zl, zrlTok & 0x07ffffffu, zl);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) stage_put(st, base + off[j], tok[j] & 0x07ffffffu, tok[j] >> 27);
+                if (f.needEob) stage_put(st, base + off[8], eobTok & 0x07ffffffu, eobBits);
+            } else {
+                overflow = true;
             }
         }
     }

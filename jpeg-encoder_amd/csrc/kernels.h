@@ -35,6 +35,9 @@ struct KGeom {
     long long blocksPerImage;
     long long imageStrideBytes;
     int tableStride;             // entries between the Huffman table sets of consecutive images (0: one shared set)
+    // One byte per block of the band (or batch), written by the transform: bit k is set when the
+    // block's k-th group of eight zig-zag ordered coefficients is not all zero.
+    const unsigned char* groupMask;
     // Encoder::multiplyColorChannelBy calls made after convertToYCbCr, in call order.
     int nGains;
     struct {
@@ -87,8 +90,9 @@ constexpr int kStuffChunk = 4096;   // unstuffed bytes handled by one workgroup 
 // Fused colour conversion + subsampling + DCT + quantization + zig-zag.  d_clearHist, when
 // given, is one histogram set (uint64[4][256]) the kernel clears on the side for a following
 // launch_histogram(..., clear = false).
-hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef, hipStream_t s,
-                            unsigned long long* d_clearHist = nullptr);
+// d_gmask receives one byte per block: which of its eight groups of eight coefficients are not all zero.
+hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef,
+                            unsigned char* d_gmask, hipStream_t s, unsigned long long* d_clearHist = nullptr);
 
 // Pixel filter (JPEG_HIP_FILTER_*) over `rows` rows of `width` pixels: src in sampleFormat
 // with srcStride bytes per row, dst float RGB with 3 * width floats per row (may be src).

@@ -111,6 +111,19 @@ __device__ __forceinline__ float clamp_coef(float v) {
     return __builtin_fminf(__builtin_fmaxf(v, -COEF_LIMIT), COEF_LIMIT);   // a NaN becomes -COEF_LIMIT
 }
 
+// Which of a block's eight groups of eight zig-zag ordered coefficients (16 bytes each) hold a
+// non-zero value: bit k for group k.  The entropy stage reads this byte per block instead of
+// looking at the empty groups themselves.
+__device__ __forceinline__ u32 group_mask(const u32 (&p)[32]) {
+    u32 m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const u32 any = p[4 * k] | p[4 * k + 1] | p[4 * k + 2] | p[4 * k + 3];
+        m |= (any != 0 ? 1u : 0u) << k;
+    }
+    return m;
+}
+
 // One colour channel of one pixel (SIMD256.h:155-186).  The reference also adds the
 // matrix's "0 * 1" term; adding +0.0f can only turn a -0.0 into +0.0, which no later
 // step can observe in the integer coefficients, so it is left out.
@@ -180,7 +193,8 @@ __device__ __forceinline__ void clear_histograms(u64* __restrict__ hist) {
 
 __global__ __launch_bounds__(kGenThreads) void k_transform_generic(KGeom g, const void* __restrict__ rgb,
                                                                    const float* __restrict__ qtab,
-                                                                   int16_t* __restrict__ coef, u64* __restrict__ clearHist) {
+                                                                   int16_t* __restrict__ coef, unsigned char* __restrict__ gmask,
+                                                                   u64* __restrict__ clearHist) {
     clear_histograms(clearHist);
     __shared__ float samples[kGenThreads * 65];
     __shared__ float q[3 * 64];
@@ -241,6 +255,7 @@ __global__ __launch_bounds__(kGenThreads) void k_transform_generic(KGeom g, cons
     uint4* dst = (uint4*)(coef + b * 64);
 #pragma unroll
     for (int i = 0; i < 8; ++i) dst[i] = make_uint4(packed[4 * i], packed[4 * i + 1], packed[4 * i + 2], packed[4 * i + 3]);
+    gmask[b] = (unsigned char)group_mask(packed);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -387,11 +402,13 @@ constexpr int kStagePitch = 144;
 template <int kRounds, bool kClamp = false>
 __device__ __forceinline__ void finish_block_staged(f2 (&a)[32], const float* __restrict__ rhi,
                                                     const float* __restrict__ rlo, unsigned char* stage,
-                                                    int16_t* __restrict__ waveBase, int blockStride, int count) {
+                                                    int16_t* __restrict__ waveBase, unsigned char* __restrict__ waveMask,
+                                                    int blockStride, int count) {
     const int lane = threadIdx.x & 63;
     constexpr int kPerRound = 64 / kRounds;
     u32 p[32];
     transform_quantize_pairs<kClamp>(a, rhi, rlo, p);
+    if (lane < count) waveMask[lane * blockStride] = (unsigned char)group_mask(p);
 #pragma unroll
     for (int round = 0; round < kRounds; ++round) {
         if (kRounds == 1 || lane / kPerRound == round) {
@@ -423,10 +440,12 @@ __device__ __forceinline__ void finish_block_staged(f2 (&a)[32], const float* __
 // half-wave rounds through a 32-block stage.
 __device__ __forceinline__ void finish_block_staged_y(f2 (&a)[32], const float* __restrict__ rhi,
                                                       const float* __restrict__ rlo, unsigned char* stage,
-                                                      int16_t* __restrict__ waveBase, int mcuCount) {
+                                                      int16_t* __restrict__ waveBase, unsigned char* __restrict__ waveMask,
+                                                      int mcuCount) {
     const int lane = threadIdx.x & 63;
     u32 p[32];
     transform_quantize_pairs(a, rhi, rlo, p);
+    if ((lane >> 2) < mcuCount) waveMask[(lane >> 2) * 6 + (lane & 3)] = (unsigned char)group_mask(p);
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
         if ((lane >> 5) == round) {
@@ -461,7 +480,7 @@ constexpr int kChromaPitch = 68;   // floats per block in LDS: keeps 16-byte row
 
 __global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned char* __restrict__ rgb,
                                                        const float* __restrict__ qtab, int16_t* __restrict__ coef,
-                                                       u64* __restrict__ clearHist) {
+                                                       unsigned char* __restrict__ gmask, u64* __restrict__ clearHist) {
     clear_histograms(clearHist);
     __shared__ __attribute__((aligned(16))) float chroma[2 * k420Mcus * kChromaPitch];
     __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 32 * kStagePitch];
@@ -527,7 +546,7 @@ __global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned c
         // stride, so the four blocks of an MCU are addressed through their MCU.
         const int waveMcus = mcuCount - wave * 16;   // MCUs of this wave that exist (may be <= 0)
         finish_block_staged_y(a, rhi, rlo, stage + wave * 32 * kStagePitch, coef + (mBase + wave * 16) * 6 * 64,
-                              waveMcus);
+                              gmask + (mBase + wave * 16) * 6, waveMcus);
     }
     __syncthreads();
     if (tid < 2 * k420Mcus) {
@@ -541,7 +560,7 @@ __global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned c
             a[2 * i + 1] = (f2){t.z, t.w};
         }
         finish_block_staged<2>(a, rhi + 64 * (1 + ch), rlo + 64 * (1 + ch), stage + wave * 32 * kStagePitch,
-                               coef + (mBase * 6 + 4 + ch) * 64, 6, mcuCount);
+                               coef + (mBase * 6 + 4 + ch) * 64, gmask + mBase * 6 + 4 + ch, 6, mcuCount);
     }
 }
 
@@ -554,7 +573,8 @@ constexpr int k444Positions = 64;
 
 __global__ __launch_bounds__(3 * k444Positions) void k_transform_444(KGeom g, const unsigned char* __restrict__ rgb,
                                                                      const float* __restrict__ qtab,
-                                                                     int16_t* __restrict__ coef, u64* __restrict__ clearHist) {
+                                                                     int16_t* __restrict__ coef, unsigned char* __restrict__ gmask,
+                                                                     u64* __restrict__ clearHist) {
     clear_histograms(clearHist);
     const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* rhi = qtab + 192 + 64 * c;
@@ -594,7 +614,7 @@ __global__ __launch_bounds__(3 * k444Positions) void k_transform_444(KGeom g, co
         }
         __builtin_amdgcn_sched_barrier(0);   // row pair by row pair: bounds the live registers
     }
-    finish_block_staged<2>(a, rhi, rlo, stage + c * 32 * kStagePitch, coef + (m0w * 3 + c) * 64, 3, count);
+    finish_block_staged<2>(a, rhi, rlo, stage + c * 32 * kStagePitch, coef + (m0w * 3 + c) * 64, gmask + m0w * 3 + c, 3, count);
 }
 
 // Pixel filters in front of the transform.  One thread per pixel; in place when src == dst.
@@ -867,7 +887,8 @@ constexpr int kRowsMaxBpm = 8;
 template <bool kFloat>
 __global__ __launch_bounds__(64 * kRowsMaxBpm) void k_transform_rows(KGeom g, const unsigned char* __restrict__ rgb,
                                                                      const float* __restrict__ qtab,
-                                                                     int16_t* __restrict__ coef, u64* __restrict__ clearHist) {
+                                                                     int16_t* __restrict__ coef, unsigned char* __restrict__ gmask,
+                                                                     u64* __restrict__ clearHist) {
     clear_histograms(clearHist);
     __shared__ __attribute__((aligned(16))) unsigned char stage[kRowsMaxBpm * 32 * kStagePitch];
     const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // block inside the MCU
@@ -900,7 +921,7 @@ __global__ __launch_bounds__(64 * kRowsMaxBpm) void k_transform_rows(KGeom g, co
         else gather_block_rows<4>(g, pix, sx0, sy0, hf, nw, nh, interior, c, a);
     }
     finish_block_staged<2, kFloat>(a, qtab + 192 + 64 * c, qtab + 384 + 64 * c, stage + k * 32 * kStagePitch,
-                                   coef + (mBase * g.bpm + k) * 64, g.bpm, count);
+                                   coef + (mBase * g.bpm + k) * 64, gmask + mBase * g.bpm + k, g.bpm, count);
 }
 
 // The row-wise kernel takes factors 1, 2 and 4 and up to eight blocks per MCU (every scheme
@@ -921,31 +942,31 @@ static bool scheme_is(const KGeom& g, int wf, int hf, int method) {
     return true;
 }
 
-hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef, hipStream_t s,
-                            unsigned long long* d_clearHist) {
+hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef,
+                            unsigned char* d_gmask, hipStream_t s, unsigned long long* d_clearHist) {
     const bool bytesAligned = g.sampleFormat == JPEG_HIP_RGB8 && g.stages == JPEG_HIP_STAGE_ALL && g.nGains == 0 &&
                               (g.strideBytes & 3) == 0 && ((uintptr_t)d_rgb & 3) == 0 &&
                               (g.batch == 1 || (g.imageStrideBytes & 3) == 0);
     if (bytesAligned && scheme_is(g, 2, 2, JPEG_HIP_AVERAGE)) {
         const long long grid = (g.nMcu + k420Mcus - 1) / k420Mcus;
         hipLaunchKernelGGL(k_transform_420, dim3((unsigned)grid), dim3(256), 0, s, g, (const unsigned char*)d_rgb, d_qtab,
-                           d_coef, d_clearHist);
+                           d_coef, d_gmask, d_clearHist);
     } else if (bytesAligned && scheme_is(g, 1, 1, JPEG_HIP_SUBSAMPLING)) {
         const long long grid = (g.nMcu + k444Positions - 1) / k444Positions;
         hipLaunchKernelGGL(k_transform_444, dim3((unsigned)grid), dim3(3 * k444Positions), 0, s, g,
-                           (const unsigned char*)d_rgb, d_qtab, d_coef, d_clearHist);
+                           (const unsigned char*)d_rgb, d_qtab, d_coef, d_gmask, d_clearHist);
     } else if (bytesAligned && rows_kernel_takes(g)) {
         const long long grid = (g.nMcu + 63) / 64;
         hipLaunchKernelGGL(k_transform_rows<false>, dim3((unsigned)grid), dim3(64 * g.bpm), 0, s, g,
-                           (const unsigned char*)d_rgb, d_qtab, d_coef, d_clearHist);
+                           (const unsigned char*)d_rgb, d_qtab, d_coef, d_gmask, d_clearHist);
     } else if (g.sampleFormat == JPEG_HIP_RGBF32 && g.nGains == 0 && rows_kernel_takes(g)) {   // any stages, any scheme
         const long long grid = (g.nMcu + 63) / 64;
         hipLaunchKernelGGL(k_transform_rows<true>, dim3((unsigned)grid), dim3(64 * g.bpm), 0, s, g,
-                           (const unsigned char*)d_rgb, d_qtab, d_coef, d_clearHist);
+                           (const unsigned char*)d_rgb, d_qtab, d_coef, d_gmask, d_clearHist);
     } else {
         const long long grid = (g.totalBlocks + kGenThreads - 1) / kGenThreads;
         hipLaunchKernelGGL(k_transform_generic, dim3((unsigned)grid), dim3(kGenThreads), 0, s, g, d_rgb, d_qtab, d_coef,
-                           d_clearHist);
+                           d_gmask, d_clearHist);
     }
     return hipGetLastError();
 }

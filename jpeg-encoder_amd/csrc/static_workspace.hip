@@ -58,7 +58,7 @@ int fail(jpeg_hip_ctx* ctx, int status, const char* msg) {
 
 // The context's workspace buffers, swapped for slices of the array and put back on the way out.
 struct Loan {
-    static constexpr int kCount = 11;
+    static constexpr int kCount = 12;
     jpeg_hip_ctx* ctx;
     DevBuf* slot[kCount];
     DevBuf saved[kCount];
@@ -66,7 +66,7 @@ struct Loan {
     bool savedQtabOnDevice;
     explicit Loan(jpeg_hip_ctx* c) : ctx(c) {
         DevBuf* all[kCount] = {&c->coef, &c->qtab, &c->hist, &c->tables, &c->ivOff, &c->ffCount, &c->groupSum, &c->result,
-                               &c->unstuffed, &c->tileState, &c->histDone};
+                               &c->unstuffed, &c->tileState, &c->histDone, &c->gmask};
         for (int i = 0; i < kCount; ++i) {
             slot[i] = all[i];
             saved[i] = *all[i];
@@ -116,7 +116,7 @@ int jpeg_hip_encode_static(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_form
     // Everything but the unstuffed stream has a size fixed by the geometry; the stream (with
     // the 0xFF counts that go with it, 4 bytes per 4 KiB chunk and 8 per 64 chunks) gets the rest.
     const WorkspaceSizes fixed = workspace_sizes(g, 1, 0);
-    const size_t fixedBytes = round256(fixed.coef) + round256(fixed.qtab) + round256(fixed.hist) + round256(fixed.tables) +
+    const size_t fixedBytes = round256(fixed.coef) + round256(fixed.gmask) + round256(fixed.qtab) + round256(fixed.hist) + round256(fixed.tables) +
                               round256(fixed.ivOff) + round256(fixed.result) + round256(fixed.tileState) + 256 /* histDone */;
     const size_t margin = 64u << 10;   // rounding of the slices, the counts of a partial chunk
     if (fixedBytes + margin + (1u << 20) > kStaticWorkspaceBytes)
@@ -142,6 +142,7 @@ int jpeg_hip_encode_static(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_form
         Loan loan(ctx);
         unsigned char* cursor = base;
         loan.lend(ctx->coef, cursor, sz.coef);
+        loan.lend(ctx->gmask, cursor, sz.gmask);
         loan.lend(ctx->qtab, cursor, sz.qtab);
         loan.lend(ctx->hist, cursor, sz.hist);
         loan.lend(ctx->tables, cursor, sz.tables);

@@ -303,3 +303,55 @@ def test_device_rows_off_dword_boundaries(ctx):
         prm = B.make_params(w, h, T.SCHEMES[scheme], qt)
         n = ctx.encode(d_buf.data_ptr() + off, B.RGB8, stride, prm, d_out.data_ptr(), d_out.numel())
         assert d_out[:n].cpu().numpy().tobytes() == want, (w, h, scheme, pad, off)
+
+
+@pytest.mark.parametrize("writer", ["blocks", "groups"])
+def test_tables_from_a_histogram_that_undercounts(ctx, writer, monkeypatch):
+    """The histograms the tables are built from also tell how much of the stream buffer has
+    to be cleared.  Tables from counts that do not cover the image (a flat image's tables kept
+    for a busy one, a caller's own counts) must not leave a stream with stale bytes in it:
+    the stage notices that it wrote past the cleared part and runs again."""
+    import torch
+    if writer == "groups":
+        monkeypatch.setenv("JPEGENC_GROUP_MIN_BLOCKS", "0")
+    qt = T.quality_tables(90)
+    busy = synth.generate("noise", 640, 480, seed=5)
+    prm = B.make_params(640, 480, T.SCHEME_420, qt)
+    d_out = torch.full((4 << 20,), 0xFF, dtype=torch.uint8, device="cuda")
+    c = B.Context(0)
+    try:
+        # leave stale bytes in the context's stream buffer: a long stream first
+        assert c.encode_host(busy, prm) == O.encode(busy, T.SCHEME_420, qt).jpeg
+        c.begin(prm)
+        c.upload_pixels(busy)
+        c.transform()
+        hist = c.histograms()
+        c.build_huffman(np.minimum(hist, 1))        # every symbol once: the same symbols, a tiny bit count
+        lengths, codes = c.get_huffman()
+        O.set_fixed_tables(lengths, codes)
+        try:
+            want = O.encode(busy, T.SCHEME_420, qt).scan
+        finally:
+            O.set_fixed_tables()
+        n = c.emit_scan(d_out.data_ptr(), d_out.numel())
+        assert d_out[:n].cpu().numpy().tobytes() == want
+        # new pixels under the tables of the image before: the bound of that image is forgotten
+        flat = np.full((480, 640, 3), 128, np.uint8)
+        c.begin(prm)
+        c.upload_pixels(flat)
+        c.transform()
+        c.build_huffman(c.histograms())
+        c.emit_scan(d_out.data_ptr(), d_out.numel())
+        std_lengths, std_codes = B.standard_huffman()
+        c.set_huffman(std_lengths, std_codes)
+        c.upload_pixels(busy)
+        c.transform()
+        O.set_fixed_tables(std_lengths, std_codes)
+        try:
+            want = O.encode(busy, T.SCHEME_420, qt).scan
+        finally:
+            O.set_fixed_tables()
+        n = c.emit_scan(d_out.data_ptr(), d_out.numel())
+        assert d_out[:n].cpu().numpy().tobytes() == want
+    finally:
+        c.close()
