@@ -14,6 +14,8 @@ Rank 0 prints one JSON line.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -101,6 +103,36 @@ def stage_rooflines(lay, images, out_bytes, kern_ms):
     return res
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: this process starts the N ranks
+    itself (one per GPU, environment as torch.distributed.run would set it), never touches a
+    GPU, relays rank 0's JSON line and fails if any rank fails."""
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    have = torch.cuda.device_count()   # counting devices does not initialise the GPU
+    if backend == "nccl" and have < n:
+        print("bench.py: --gpus %d asked for but %d GPU(s) are visible; not running a smaller job under that name"
+              % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print("bench.py: ranks failed (rank, exit code): %s" % bad, file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +153,8 @@ def main():
                     help="diagnostic: stop after the transform and the histogram pass (no file is written)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -136,9 +170,31 @@ def main():
             local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if args.gpus != world:
         if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+            print("bench.py: --gpus %d but WORLD_SIZE %d: the launcher and the arguments disagree" % (args.gpus, world),
+                  file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # The histogram all-reduce runs inside the library (jpeg_hip_encode_sharded /
+    # jpeg_hip_allreduce_histograms) on RCCL communicators the library creates: rank 0 makes the
+    # ids, torch.distributed only carries them to the other ranks (and the barriers and the
+    # timing reduction of this harness).  One communicator per image in flight.
+    use_rccl = world > 1 and dist.get_backend() == "nccl"
+
+    def make_comm():
+        uid = torch.from_numpy(B.comm_unique_id()).to(dev) if rank == 0 else torch.zeros(128, dtype=torch.uint8, device=dev)
+        dist.broadcast(uid, 0)
+        return B.Communicator(uid.cpu().numpy(), rank, world, local_rank)
+
+    comms = [make_comm()] if use_rccl else [None]
+    collective = None
+    if world > 1:
+        names = [None] * world
+        dist.all_gather_object(names, "cuda:%d %s" % (local_rank, torch.cuda.get_device_name(local_rank)))
+        collective = {"backend": "rccl: ncclAllReduce of uint64[4][256] on the encoder's stream (libjpegenc_hip), "
+                                 "torch.distributed backend %s for set-up and timing" % dist.get_backend()
+                      if use_rccl else "%s through host memory (rehearsal)" % dist.get_backend(),
+                      "world_size": dist.get_world_size(), "devices": names}
 
     width, height, sname, quality, kind, desc = WORKLOADS[args.workload]
     scheme, qt = T.SCHEMES[sname], T.quality_tables(quality)
@@ -187,6 +243,8 @@ def main():
         if batch:
             lens = ctx.encode_batch(rgb.data_ptr(), B.RGB8, stride, image_stride, batch, params, out.data_ptr(), cap)
             return int(lens.sum())
+        if use_rccl and not args.analyze_only:
+            return ctx.encode_sharded(comms[0], rgb.data_ptr(), B.RGB8, stride, params, out.data_ptr(), cap)
         ctx.analyze_band(rgb.data_ptr(), B.RGB8, stride, params, hist.data_ptr())
         if args.analyze_only:
             return 0
@@ -220,6 +278,8 @@ def main():
     lanes = [(ctx, hist, ext, out)]
 
     def add_lanes(total):
+        while use_rccl and len(comms) < total:
+            comms.append(make_comm())
         while len(lanes) < total:
             c = B.Context(local_rank)
             c.set_profiling(True)
@@ -234,8 +294,10 @@ def main():
         c.analyze_band(rgb.data_ptr(), B.RGB8, stride, params, h.data_ptr())
 
     def reduce(k):
-        _, h, e, _ = lanes[k]
-        if world > 1 and not args.standard_huffman:
+        c, h, e, _ = lanes[k]
+        if use_rccl and not args.standard_huffman:
+            c.allreduce_histograms(comms[k], h.data_ptr())
+        elif world > 1 and not args.standard_huffman:
             cur = torch.cuda.current_stream()
             cur.wait_stream(e)
             if host_reduce:
@@ -323,6 +385,7 @@ def main():
                        "parallelism": ("frames-per-gpu x%d" if batch else "band-per-gpu x%d") % world,
                        "images_in_flight": depth,
                        "jpeg_bytes_rank0": int(n_out)},
+            "collective": collective,
             "roofline": {"bound": "hbm", "kernel": "fused transform (colour, subsample, DCT, quantize, zig-zag)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
@@ -380,6 +443,9 @@ def main():
         print(json.dumps(res), flush=True)
     for lane in lanes:
         lane[0].close()
+    for c in comms:
+        if c is not None:
+            c.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -294,6 +294,30 @@ int jpeg_hip_finish_band(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t*
 int jpeg_hip_finish_band_start(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t* d_out, int64_t out_capacity);
 int jpeg_hip_finish_band_wait(jpeg_hip_ctx* ctx, int64_t* out_len);
 
+/* The whole sharded encode of one rank in one call, for a host that holds an RCCL
+ * communicator (an ncclComm_t, passed as void* so that this header needs no RCCL header):
+ * jpeg_hip_analyze_band, one ncclAllReduce (sum, 4 x 256 uint64) of the histograms on the
+ * context's stream, jpeg_hip_finish_band.  It stands in for Encoder::serialize
+ * (Encoder.cpp:439-488) run on an image that several GPUs hold one band each of: every rank
+ * derives the same tables from the summed histograms (Encoder::createHuffmanTable,
+ * Encoder.cpp:368-416) and writes its piece of the file; the pieces concatenate in rank order.
+ * params->mcu_row_begin / mcu_row_end name this rank's band, restart_interval must be set
+ * (bands start on interval boundaries).  Collective: every rank of the communicator has to call
+ * it, in the same order as the others. */
+int jpeg_hip_encode_sharded(jpeg_hip_ctx* ctx, void* rccl_comm, const void* d_rgb_band, int sample_format,
+                            int64_t stride_bytes, const jpeg_hip_params* params, uint8_t* d_out, int64_t out_capacity,
+                            int64_t* out_len);
+/* The exchange step alone, for callers that keep several images in flight with
+ * jpeg_hip_analyze_band / jpeg_hip_finish_band_start / _wait: sums d_hist (uint64[4][256], as
+ * jpeg_hip_analyze_band filled it) over the ranks in place, on the context's stream. */
+int jpeg_hip_allreduce_histograms(jpeg_hip_ctx* ctx, void* rccl_comm, uint64_t* d_hist);
+/* Communicator set-up for hosts without RCCL bindings of their own (ncclGetUniqueId,
+ * ncclCommInitRank, ncclCommDestroy): rank 0 makes the 128-byte id and hands it to the other
+ * ranks by whatever channel the job has; every rank then creates its communicator on its GPU. */
+int jpeg_hip_comm_unique_id(uint8_t id[128]);
+int jpeg_hip_comm_create(const uint8_t id[128], int rank, int world_size, int device_id, void** out_comm);
+void jpeg_hip_comm_destroy(void* comm);
+
 /* Timing of the last jpeg_hip_encode / analyze / finish in milliseconds, measured with HIP
  * events on the context's stream: [0] fused transform kernel, [1] histogram kernel,
  * [2] entropy kernels (clears, bit writer, stuffing), [3] host table build.

@@ -25,7 +25,7 @@ EXPORTS = [
     "jpeg_hip_huffman_from_histogram", "jpeg_hip_standard_huffman", "jpeg_hip_write_dht", "jpeg_hip_write_headers", "jpeg_hip_set_huffman",
     "jpeg_hip_build_huffman", "jpeg_hip_get_huffman", "jpeg_hip_emit_scan", "jpeg_hip_emit_scan_host",
     "jpeg_hip_get_coefficients",
-    "jpeg_hip_coefficients_device", "jpeg_hip_analyze_band", "jpeg_hip_finish_band", "jpeg_hip_finish_band_start", "jpeg_hip_finish_band_wait", "jpeg_hip_set_profiling",
+    "jpeg_hip_coefficients_device", "jpeg_hip_encode_sharded", "jpeg_hip_allreduce_histograms", "jpeg_hip_comm_unique_id", "jpeg_hip_comm_create", "jpeg_hip_comm_destroy", "jpeg_hip_analyze_band", "jpeg_hip_finish_band", "jpeg_hip_finish_band_start", "jpeg_hip_finish_band_wait", "jpeg_hip_set_profiling",
     "jpeg_hip_get_timings", "jpeg_hip_decode_info", "jpeg_hip_decode", "jpeg_hip_decode_host",
     "jpeg_hip_decoded_coefficients", "jpeg_hip_psnr", "jpeg_hip_filter_pixels", "jpeg_hip_get_pixels", "jpeg_hip_channel_gain",
 ]
@@ -122,6 +122,12 @@ def lib():
         L.jpeg_hip_finish_band.argtypes = [vp, vp, vp, i64, C.POINTER(i64)]
         L.jpeg_hip_finish_band_start.argtypes = [vp, vp, vp, i64]
         L.jpeg_hip_finish_band_wait.argtypes = [vp, C.POINTER(i64)]
+        L.jpeg_hip_encode_sharded.argtypes = [vp, vp, vp, i32, i64, C.POINTER(Params), vp, i64, C.POINTER(i64)]
+        L.jpeg_hip_allreduce_histograms.argtypes = [vp, vp, vp]
+        L.jpeg_hip_comm_unique_id.argtypes = [vp]
+        L.jpeg_hip_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+        L.jpeg_hip_comm_destroy.argtypes = [vp]
+        L.jpeg_hip_comm_destroy.restype = None
         L.jpeg_hip_set_profiling.argtypes = [vp, i32]
         L.jpeg_hip_get_timings.argtypes = [vp, vp]
         _lib = L
@@ -211,6 +217,37 @@ def write_headers(params, lengths, codes):
     if n < 0:
         raise JpegHipError(n, "write_headers")
     return out[:n].tobytes()
+
+
+def comm_unique_id():
+    """128 bytes that every rank of a job passes to Communicator (made by one rank, handed to the others)."""
+    buf = np.zeros(128, np.uint8)
+    st = lib().jpeg_hip_comm_unique_id(_np(buf))
+    if st != OK:
+        raise JpegHipError(st, "ncclGetUniqueId failed")
+    return buf
+
+
+class Communicator:
+    """An RCCL communicator created through the library (ncclCommInitRank on `device`)."""
+
+    def __init__(self, unique_id, rank, world_size, device):
+        uid = np.ascontiguousarray(unique_id, np.uint8).reshape(128)
+        self._h = C.c_void_p()
+        st = lib().jpeg_hip_comm_create(_np(uid), int(rank), int(world_size), int(device), C.byref(self._h))
+        if st != OK:
+            self._h = C.c_void_p()
+            raise JpegHipError(st, "ncclCommInitRank failed (rank %d of %d on GPU %d)" % (rank, world_size, device))
+        self.rank, self.world_size, self.device = rank, world_size, device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            lib().jpeg_hip_comm_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 class Context:
@@ -362,6 +399,16 @@ class Context:
     def analyze_band(self, d_rgb, fmt, stride, params, d_hist):
         self._check(lib().jpeg_hip_analyze_band(self._h, C.c_void_p(d_rgb), fmt, stride, C.byref(params),
                                                 C.c_void_p(d_hist)))
+
+    def encode_sharded(self, comm, d_rgb, fmt, stride, params, d_out, capacity):
+        """This rank's piece of a sharded image: analyze, all-reduce of the histograms over `comm`, finish."""
+        n = C.c_int64(0)
+        self._check(lib().jpeg_hip_encode_sharded(self._h, comm.handle, C.c_void_p(d_rgb), fmt, stride, C.byref(params),
+                                                  C.c_void_p(d_out), capacity, C.byref(n)))
+        return n.value
+
+    def allreduce_histograms(self, comm, d_hist):
+        self._check(lib().jpeg_hip_allreduce_histograms(self._h, comm.handle, C.c_void_p(d_hist)))
 
     def finish_band(self, d_hist_sum, d_out, capacity):
         n = C.c_int64(0)

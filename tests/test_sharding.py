@@ -210,3 +210,38 @@ def test_full_size_bands_equal_whole_image_and_round_trip():
     mse, psnr = ctx.psnr(rgb.data_ptr(), w * 3, dec.data_ptr(), w * 3, w, h)
     assert psnr > 33.0, psnr
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_sharded_entry_point_over_an_rccl_communicator_of_one():
+    """jpeg_hip_encode_sharded (analyze, ncclAllReduce on the context's stream, finish) with a
+    world of one rank: the same bytes as jpeg_hip_encode with the same restart interval, and as
+    the oracle; then the exchange step alone between the two halves."""
+    dev = torch.device("cuda", 0)
+    qt = T.quality_tables(90)
+    comm = B.Communicator(B.comm_unique_id(), 0, 1, 0)
+    ctx, plain = B.Context(0), B.Context(0)
+    try:
+        for (w, h, scheme, std) in [(640, 360, "420", False), (333, 210, "444", False), (640, 360, "420", True)]:
+            img = synth.generate("natural", w, h, seed=w)
+            enc = sharding.HipBandEncoder(ctx, B, w, h, T.SCHEMES[scheme], qt, 1, 0)
+            prm = enc.params
+            prm.standard_huffman = 1 if std else 0
+            rgb = torch.from_numpy(img).to(dev)
+            out_a = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+            out_b = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+            n_a = ctx.encode_sharded(comm, rgb.data_ptr(), B.RGB8, w * 3, prm, out_a.data_ptr(), out_a.numel())
+            n_b = plain.encode(rgb.data_ptr(), B.RGB8, w * 3, prm, out_b.data_ptr(), out_b.numel())
+            got = out_a[:n_a].cpu().numpy().tobytes()
+            assert got == out_b[:n_b].cpu().numpy().tobytes(), (w, h, scheme, std)
+            if not std:
+                assert got == O.encode(img, T.SCHEMES[scheme], qt, restart_interval=prm.restart_interval).jpeg
+                hist = torch.zeros((4, 256), dtype=torch.int64, device=dev)
+                ctx.analyze_band(rgb.data_ptr(), B.RGB8, w * 3, prm, hist.data_ptr())
+                ctx.allreduce_histograms(comm, hist.data_ptr())
+                n_c = ctx.finish_band(hist.data_ptr(), out_a.data_ptr(), out_a.numel())
+                assert out_a[:n_c].cpu().numpy().tobytes() == got
+    finally:
+        ctx.close()
+        plain.close()
+        comm.close()
