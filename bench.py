@@ -220,13 +220,13 @@ def main():
     stride = width * 3
     if batch:
         image_stride = stride * height
+        # The inputs come from the library's own generator, one launch for all frames (the same
+        # bytes as synth / synth_torch, which the tests compare it with).
         rgb = torch.empty(batch * image_stride, dtype=torch.uint8, device=dev)
-        for k in range(batch):
-            frame = synth_torch.generate(kind, width, height, seed=1000 + rank * batch + k, device=dev)
-            rgb[k * image_stride:(k + 1) * image_stride] = frame.reshape(-1)
-        del frame
+        ctx.synthetic_images(kind, width, 0, height, 1000 + rank * batch, rgb.data_ptr(), stride, image_stride, batch)
     else:
-        rgb = synth_torch.generate(kind, width, height, device=dev, y0=y0, y1=y1)
+        rgb = torch.empty((y1 - y0) * stride, dtype=torch.uint8, device=dev)
+        ctx.synthetic_images(kind, width, y0, y1, 42 if kind == "noise" else 1, rgb.data_ptr(), stride)
     hist = torch.zeros((4, 256), dtype=torch.int64, device=dev)
     # Output capacity: the worst case bound is huge; 1.5 bytes per pixel of the band plus
     # slack covers every workload here (noise at q=100 needs about 1.1 B/px in 4:2:0 and

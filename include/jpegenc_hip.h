@@ -358,6 +358,17 @@ int jpeg_hip_decoded_coefficients(jpeg_hip_ctx* ctx, int16_t* h_out, int64_t cap
 int jpeg_hip_psnr(jpeg_hip_ctx* ctx, const uint8_t* d_a, int64_t stride_a, const uint8_t* d_b, int64_t stride_b,
                   int32_t width, int32_t height, double* mse, double* psnr);
 
+/* ---- harness utility ------------------------------------------------------------------------ */
+
+/* Fills device memory with the synthetic test images of the benchmark and the tests (no
+ * counterpart in the reference, whose driver reads files): rows y0..y1 of `count` RGB8 images of
+ * `width` pixels, image k (seed + k) starting at d_out + k * image_stride_bytes.  kind 0: uniform
+ * noise, byte(x, y, c) = mix32(seed ^ (3 * (y * width + x) + c)) >> 24; kind 1: triangle-wave
+ * colour ramps plus a 4-bit hashed dither ("natural-like").  Integer arithmetic only: the
+ * same bytes as the host generators of the tests. */
+int jpeg_hip_synthetic_images(jpeg_hip_ctx* ctx, int kind, int32_t width, int32_t y0, int32_t y1, uint32_t seed,
+                              uint8_t* d_out, int64_t stride_bytes, int64_t image_stride_bytes, int count);
+
 #ifdef __cplusplus
 }
 #endif

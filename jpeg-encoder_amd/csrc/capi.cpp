@@ -1562,6 +1562,18 @@ int jpeg_hip_decoded_coefficients(jpeg_hip_ctx* ctx, int16_t* h_out, int64_t cap
     return JPEG_HIP_OK;
 }
 
+int jpeg_hip_synthetic_images(jpeg_hip_ctx* ctx, int kind, int32_t width, int32_t y0, int32_t y1, uint32_t seed,
+                              uint8_t* d_out, int64_t stride_bytes, int64_t image_stride_bytes, int count) {
+    if (!ctx || !d_out || (kind != 0 && kind != 1) || width < 1 || y0 < 0 || y1 <= y0 || count < 1 ||
+        stride_bytes < (int64_t)width * 3)
+        return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    ENTER_DEVICE(ctx);
+    HIP_TRY(ctx, launch_synthetic_images(d_out, kind, width, y1 - y0, y0, seed, stride_bytes, image_stride_bytes, count,
+                                         ctx->stream));
+    HIP_TRY(ctx, wait_stream(ctx));
+    return JPEG_HIP_OK;
+}
+
 int jpeg_hip_psnr(jpeg_hip_ctx* ctx, const uint8_t* d_a, int64_t stride_a, const uint8_t* d_b, int64_t stride_b,
                   int32_t width, int32_t height, double* mse, double* psnr) {
     if (!ctx || !d_a || !d_b || width < 1 || height < 1 || stride_a < (int64_t)width * 3 || stride_b < (int64_t)width * 3)

@@ -58,6 +58,10 @@ hipError_t launch_planes_to_rgb(const DGeom& g, const float* d_planes, uint8_t* 
 hipError_t launch_squared_error(const uint8_t* d_a, long long strideA, const uint8_t* d_b, long long strideB, int width,
                                 int height, unsigned long long* d_sum, hipStream_t s);
 
+// Rows y0.. of `count` synthetic images (kind 0 noise, 1 natural-like; seeds seed, seed + 1, ...).
+hipError_t launch_synthetic_images(unsigned char* d_out, int kind, int width, int rows, int y0, unsigned seed,
+                                   long long strideBytes, long long imageStrideBytes, int count, hipStream_t s);
+
 }  // namespace jpeghip
 
 #endif

@@ -135,4 +135,53 @@ hipError_t launch_squared_error(const uint8_t* d_a, long long strideA, const uin
     return hipGetLastError();
 }
 
+// ---- synthetic images of the benchmark and the tests ----------------------------------------
+// Integer-only, the same bytes on every machine: mix32 is a 32-bit avalanche hash; "noise" is
+// byte(x, y, c) = mix32(seed ^ (3 * (y * W + x) + c)) >> 24, "natural" a set of triangle-wave
+// colour ramps plus a 4-bit hashed dither.  One thread per byte, rows y0.. of `count` images whose
+// seeds are seed, seed + 1, ...
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_synthetic_images(unsigned char* __restrict__ out, int kind, int width, int rows,
+                                                          int y0, unsigned seed, long long strideBytes,
+                                                          long long imageStrideBytes) {
+    const int xb = blockIdx.x * 256 + threadIdx.x;   // byte inside the row
+    if (xb >= width * 3) return;
+    const unsigned y = (unsigned)(y0 + blockIdx.y), x = (unsigned)xb / 3u, c = (unsigned)xb - 3u * x;
+    const unsigned idx = (y * (unsigned)width + x) * 3u + c;
+    const unsigned h = mix32((seed + blockIdx.z) ^ idx);
+    unsigned v;
+    if (kind == 0) {
+        v = h >> 24;
+    } else {
+        const unsigned t = (x * (3u + c) + y * (5u - c)) >> 3;
+        const int lo = (int)(t & 255u);
+        const int tri = ((t >> 8) & 1u) ? 255 - lo : lo;
+        int s = tri + (int)(h >> 28) - 8;
+        s = s < 0 ? 0 : (s > 255 ? 255 : s);
+        v = (unsigned)s;
+    }
+    out[(long long)blockIdx.z * imageStrideBytes + (long long)blockIdx.y * strideBytes + xb] = (unsigned char)v;
+}
+
+hipError_t launch_synthetic_images(unsigned char* d_out, int kind, int width, int rows, int y0, unsigned seed,
+                                   long long strideBytes, long long imageStrideBytes, int count, hipStream_t s) {
+    // the grid's y and z extents are limited to 65535
+    for (int r0 = 0; r0 < rows; r0 += 32768)
+        for (int c0 = 0; c0 < count; c0 += 32768) {
+            const int nr = rows - r0 < 32768 ? rows - r0 : 32768, nc = count - c0 < 32768 ? count - c0 : 32768;
+            hipLaunchKernelGGL(k_synthetic_images, dim3((unsigned)((width * 3 + 255) / 256), (unsigned)nr, (unsigned)nc),
+                               dim3(256), 0, s, d_out + (long long)c0 * imageStrideBytes + (long long)r0 * strideBytes, kind,
+                               width, nr, y0 + r0, seed + (unsigned)c0, strideBytes, imageStrideBytes);
+        }
+    return hipGetLastError();
+}
+
 }  // namespace jpeghip

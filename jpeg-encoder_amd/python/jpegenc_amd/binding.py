@@ -27,7 +27,7 @@ EXPORTS = [
     "jpeg_hip_get_coefficients",
     "jpeg_hip_coefficients_device", "jpeg_hip_encode_sharded", "jpeg_hip_allreduce_histograms", "jpeg_hip_comm_unique_id", "jpeg_hip_comm_create", "jpeg_hip_comm_destroy", "jpeg_hip_analyze_band", "jpeg_hip_finish_band", "jpeg_hip_finish_band_start", "jpeg_hip_finish_band_wait", "jpeg_hip_set_profiling",
     "jpeg_hip_get_timings", "jpeg_hip_decode_info", "jpeg_hip_decode", "jpeg_hip_decode_host",
-    "jpeg_hip_decoded_coefficients", "jpeg_hip_psnr", "jpeg_hip_filter_pixels", "jpeg_hip_get_pixels", "jpeg_hip_channel_gain",
+    "jpeg_hip_decoded_coefficients", "jpeg_hip_psnr", "jpeg_hip_synthetic_images", "jpeg_hip_filter_pixels", "jpeg_hip_get_pixels", "jpeg_hip_channel_gain",
 ]
 
 
@@ -128,6 +128,7 @@ def lib():
         L.jpeg_hip_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
         L.jpeg_hip_comm_destroy.argtypes = [vp]
         L.jpeg_hip_comm_destroy.restype = None
+        L.jpeg_hip_synthetic_images.argtypes = [vp, i32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, vp, i64, i64, i32]
         L.jpeg_hip_set_profiling.argtypes = [vp, i32]
         L.jpeg_hip_get_timings.argtypes = [vp, vp]
         _lib = L
@@ -471,6 +472,11 @@ class Context:
         self._check(lib().jpeg_hip_psnr(self._h, C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, width, height,
                                         C.byref(mse), C.byref(psnr)))
         return mse.value, psnr.value
+
+    def synthetic_images(self, kind, width, y0, y1, seed, d_out, stride, image_stride=0, count=1):
+        """Rows y0..y1 of `count` synthetic RGB8 images (seeds seed, seed + 1, ...) into device memory."""
+        self._check(lib().jpeg_hip_synthetic_images(self._h, {"noise": 0, "natural": 1}[kind], width, y0, y1,
+                                                    seed & 0xFFFFFFFF, C.c_void_p(d_out), stride, image_stride, count))
 
     def timings(self):
         t = np.zeros(4, np.float32)

@@ -1,0 +1,104 @@
+"""Full-size checks of the noise workload (8192 x 8192, q=100, all-ones tables), whose stream is
+far beyond what the CPU checker encodes in seconds -- 196 MB in 4:4:4, 1.56 * 10^9 bit
+positions, some 48 thousand stuffing chunks (the group sums of the stuffing pass are taken without
+any switch) -- through properties that do not depend on the size.  BitBuffer semantics as in
+BitBuffer.cpp:128-204."""
+import numpy as np
+import pytest
+import torch
+
+from jpegenc_amd import binding as B, sharding, synth, tables as T
+
+pytestmark = pytest.mark.gpu
+
+
+def test_generator_matches_the_host_generators():
+    ctx = B.Context(0)
+    try:
+        for kind in ("noise", "natural"):
+            w, h = 203, 117
+            out = torch.zeros((3, h, w, 3), dtype=torch.uint8, device="cuda")
+            ctx.synthetic_images(kind, w, 0, h, 1000, out.data_ptr(), w * 3, w * h * 3, 3)
+            for k in range(3):
+                assert np.array_equal(out[k].cpu().numpy(), synth.generate(kind, w, h, seed=1000 + k)), (kind, k)
+            # a band of rows
+            band = torch.zeros((40, w, 3), dtype=torch.uint8, device="cuda")
+            ctx.synthetic_images(kind, w, 30, 70, 7, band.data_ptr(), w * 3)
+            assert np.array_equal(band.cpu().numpy(), synth.generate(kind, w, h, seed=7)[30:70])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("sname", ["444", "420"])
+def test_noise_q100_full_size(sname):
+    w = h = 8192
+    scheme, qt = T.SCHEMES[sname], T.quality_tables(100)
+    dev = torch.device("cuda", 0)
+    ctx = B.Context(0)
+    rgb = torch.empty(h * w * 3, dtype=torch.uint8, device=dev)
+    ctx.synthetic_images("noise", w, 0, h, 42, rgb.data_ptr(), w * 3)
+    out = torch.zeros(224 << 20, dtype=torch.uint8, device=dev)
+
+    # 1. One scan, as the reference writes it.  Its length follows from the histograms and the
+    # tables (code length + amplitude bits per symbol, padded to a byte) plus one 0x00 behind every
+    # 0xFF of the entropy-coded data -- and no 0xFF of the scan may lack its 0x00.
+    prm = B.make_params(w, h, scheme, qt)
+    lay = B.compute_layout(prm)
+    n = ctx.encode(rgb.data_ptr(), B.RGB8, w * 3, prm, out.data_ptr(), out.numel())
+    lengths, codes = ctx.get_huffman()
+    ctx.begin(prm)
+    ctx.bind_pixels(rgb.data_ptr(), B.RGB8, w * 3)
+    ctx.transform()
+    hist = ctx.histograms().astype(np.int64)
+    extra = np.stack([np.arange(256), np.arange(256), np.arange(256) & 15, np.arange(256) & 15])
+    bits = int((hist * (lengths.astype(np.int64) + extra)).sum())
+    assert bits > (1500000000 if sname == "444" else 500000000)   # 1.56 * 10^9 bit positions in 4:4:4
+    header = len(B.write_headers(prm, lengths, codes))
+    scan = out[header:n - 2]
+    assert out[n - 2:n].cpu().tolist() == [0xFF, 0xD9]
+    ff = scan == 0xFF
+    pairs = int((ff[:-1] & (scan[1:] == 0)).sum())
+    assert int(ff.sum()) == pairs and not bool(ff[-1])
+    assert scan.numel() == (bits + 7) // 8 + pairs
+    whole_single_scan_len = n
+    del scan, ff
+
+    # 2. With a restart interval of one MCU row: eight bands put together are the file of one call.
+    world = 8
+    ctxs = [ctx] + [B.Context(0) for _ in range(world - 1)]
+    encs = [sharding.HipBandEncoder(ctxs[r], B, w, h, scheme, qt, world, r) for r in range(world)]
+    hists = [torch.zeros((4, 256), dtype=torch.int64, device=dev) for _ in range(world)]
+    for r, enc in enumerate(encs):
+        y0, y1 = enc.pixel_rows
+        enc.analyze(rgb[y0 * w * 3:].data_ptr(), B.RGB8, w * 3, hists[r].data_ptr())
+    for c in ctxs:
+        torch.cuda.ExternalStream(c.stream).synchronize()
+    total = torch.stack(hists).sum(0).contiguous()
+    # (the DC statistics differ from the single scan's: the predictor restarts with every interval)
+    assert np.array_equal(total.cpu().numpy()[2:], hist[2:])
+    torch.cuda.synchronize()
+    pieces = []
+    for enc in encs:
+        m = enc.finish(total.data_ptr(), out.data_ptr(), out.numel())
+        pieces.append(out[:m].clone())
+    sharded = torch.cat(pieces)
+    del pieces
+    for c in ctxs[1:]:
+        c.close()
+    prm_ri = B.make_params(w, h, scheme, qt, restart_interval=lay.mcus_per_row)
+    n_ri = ctx.encode(rgb.data_ptr(), B.RGB8, w * 3, prm_ri, out.data_ptr(), out.numel())
+    assert n_ri == sharded.numel() and torch.equal(out[:n_ri], sharded)
+    # markers, padding and restarting predictors (other DC tables) change the size only a little
+    assert abs(n_ri - whole_single_scan_len) < whole_single_scan_len // 1000
+    del sharded
+
+    # 3. The file decodes to exactly the coefficients the encoder held.
+    lay_ri = B.compute_layout(prm_ri)
+    per_mcu = [int(lay_ri.blocks[c]) // (int(lay_ri.total_blocks) // lay_ri.blocks_per_mcu) for c in range(3)]
+    held = np.concatenate([ctx.coefficients(c, lay_ri).reshape(-1, per_mcu[c], 64) for c in range(3)], axis=1).reshape(-1, 64)
+    jpg = out[:n_ri].cpu().numpy().tobytes()
+    dec = torch.zeros((h, w, 3), dtype=torch.uint8, device=dev)
+    info = ctx.decode(jpg, dec.data_ptr(), w * 3, dec.numel())
+    assert (info.width, info.height, info.restart_interval) == (w, h, lay.mcus_per_row)
+    assert np.array_equal(ctx.decoded_coefficients(info), held)
+    ctx.close()
