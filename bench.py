@@ -51,13 +51,15 @@ def algorithmic_bytes(lay):
     return 3 * px + 2 * 64 * int(lay.total_blocks)
 
 
-def measured_traffic(workload, world):
-    """HBM bytes per launch of the fused transform from the committed PMC passes (N=1 only)."""
+def measured_traffic(workload, world, frames):
+    """HBM bytes the fused transform moves per step, from the committed PMC passes (N=1 and the
+    default frame count only): FETCH_SIZE doubled for gfx950 plus WRITE_SIZE, per launch, times the
+    launches of a step (a batch pass runs the transform in two launches)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    if world != 1 or not os.path.exists(path):
+    if world != 1 or not os.path.exists(path) or (workload.startswith("batch_") and frames != 256):
         return None
     entry = json.load(open(path)).get(workload)
-    return entry["traffic_bytes_per_launch"] if entry else None
+    return entry["traffic_bytes_per_launch"] * entry.get("launches_per_step", 1) if entry else None
 
 
 def cpu_baseline(width, height, scheme, qt, kind):
@@ -389,7 +391,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fused transform (colour, subsample, DCT, quantize, zig-zag)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": measured_traffic(args.workload, world),
+                         "traffic": measured_traffic(args.workload, world, args.frames),
                          "algorithmic_bytes_per_launch": int(alg), "kernel_ms": round(float(kern_ms[0]), 4)},
             # Every stage against the same HBM peak (bytes each stage has to move / its time); the
             # histogram and bit-writer passes are bound by instruction issue, not by memory.
