@@ -160,3 +160,125 @@ def test_oracle_output_hashes_unchanged():
     want = json.load(open(os.path.join(here, "golden", "oracle_hashes.json")))
     got = {"%dx%d_%s_%s_%s_ri%d" % c: mod.digest(*c) for c in mod.cases()}
     assert got == want
+
+
+# ---- vectors assembled from literals in the reference's sources (tests/golden/make_literal_kats.py) ----
+
+LIT = KATS["literals"]
+
+
+def _segments(j):
+    """[(marker byte, segment bytes incl. marker and length)] up to and including SOS."""
+    out, pos = [(j[1], j[:2])], 2
+    while True:
+        assert j[pos] == 0xFF
+        n = (j[pos + 2] << 8) | j[pos + 3]
+        out.append((j[pos + 1], j[pos:pos + 2 + n]))
+        pos += 2 + n
+        if out[-1][0] == 0xDA:
+            return out
+
+
+def test_headers_of_the_reference_ad_hoc_frame_from_literals():
+    """1680 x 900, 4:2:2, Annex-K tables: the frame the reference's own bitBufferTest builds
+    (JPEG-Encoder-SIMD.cpp:73-86).  Oracle file and the product's host header writer against
+    the bytes that follow from the reference's struct initialisers."""
+    from jpegenc_amd import binding as B
+    img = synth.generate("natural", 1680, 900)
+    enc = O.encode(img, T.SCHEME_422, T.STANDARD_TABLES)
+    segs = _segments(enc.jpeg)
+    assert [f"{m:02x}" for m, _ in segs] == LIT["segment_order"]["markers"]
+    assert segs[0][1].hex() == LIT["soi_hex"]["hex"]
+    assert segs[1][1].hex() == LIT["app0_hex"]["hex"] == KATS["headers"]["app0_hex"]
+    assert segs[2][1].hex() == LIT["sof0_1680x900_422_hex"]["hex"]
+    assert [s[4] for _, s in segs[3:7]] == LIT["dht_layout"]["encoder_infos"]
+    for _, s in segs[3:7]:
+        assert s[:2].hex() == LIT["dht_layout"]["marker_hex"]
+        assert ((s[2] << 8) | s[3]) == 2 + 1 + 16 + sum(s[5:21]) == len(s) - 2
+    assert segs[7][1].hex() == LIT["dqt_luminance_id0_hex"]["hex"]
+    assert segs[8][1].hex() == LIT["dqt_chrominance_id1_hex"]["hex"]
+    assert segs[9][1].hex() == LIT["dqt_chrominance_id2_hex"]["hex"]
+    assert segs[10][1].hex() == LIT["sos_hex"]["hex"] == KATS["headers"]["sos_hex"]
+    assert enc.jpeg[-2:].hex() == LIT["eoi_hex"]["hex"]
+    # the product's host side writes the same header bytes (no GPU involved)
+    prm = B.make_params(1680, 900, T.SCHEME_422, T.STANDARD_TABLES)
+    assert B.write_headers(prm, enc.lengths, enc.codes) == enc.jpeg[:enc.scan_offset]
+
+
+def test_dht_of_seven_symbols_has_the_length_the_reference_struct_gives():
+    # bitBufferTest's table: id 3, AC, symbols 0..6 (JPEG-Encoder-SIMD.cpp:77-83)
+    from jpegenc_amd import binding as B
+    counts = np.zeros(256, np.uint64)
+    for s, n in zip(range(7), (1, 1, 3, 5, 6, 11, 13)):
+        counts[s] = n
+    lengths, codes, dht = O.huffman(counts, 3, 1)
+    assert dht[:2].hex() == LIT["dht_layout"]["marker_hex"]
+    assert (dht[2] << 8) | dht[3] == LIT["dht_layout"]["length_for_7_symbols"]
+    assert dht[4] == LIT["dht_layout"]["info_id3_ac"]
+    assert sorted(dht[21:]) == list(range(7))
+    assert B.write_dht(lengths, codes, 3, 1) == bytes(dht)
+
+
+@pytest.mark.parametrize("scheme", ["444", "422", "420", "411"])
+def test_sof0_sampling_bytes_from_literals(scheme):
+    enc = O.encode(synth.generate("natural", 40, 24), T.SCHEMES[scheme], T.STANDARD_TABLES)
+    j = enc.jpeg
+    assert [j[31], j[34], j[37]] == LIT["sof0_factor_bytes"][scheme]
+
+
+def _category(v):
+    for k, lo, hi in LIT["bit_category_ranges"]["ranges"]:
+        if lo <= abs(v) <= hi:
+            return k
+    raise AssertionError(v)
+
+
+def _amplitude(v, cat):
+    pattern = v if v >= 0 else (~(-v)) & 0xFFFF
+    return format(pattern & ((1 << cat) - 1), f"0{cat}b") if cat else ""
+
+
+def test_amplitude_rule_examples():
+    for v, cat, bits in LIT["amplitude_examples"]["cases"]:
+        assert _category(v) == cat and _amplitude(v, cat) == bits
+
+
+def test_scan_rebuilt_from_the_category_and_run_length_rules():
+    """The oracle's entropy-coded segment against a plain restatement of Encoder.cpp:262-352
+    (DC difference, run/size symbols with ZRL and EOB, amplitude bits) driven by the category
+    table from the literals, on the oracle's own coefficients and code tables."""
+    img = synth.generate("noise", 48, 32, seed=7)
+    enc = O.encode(img, T.SCHEME_444, T.quality_tables(50))
+    nblocks = enc.coef[0].shape[0]
+    bits = []
+    last = [0, 0, 0]
+    for b in range(nblocks):
+        for c in range(3):
+            dc_t, ac_t = (0, 2) if c == 0 else (1, 3)
+            blk = enc.coef[c][b].astype(int)
+            diff = int(blk[0]) - last[c]
+            last[c] = int(blk[0])
+            cat = _category(diff)
+            bits.append(format(int(enc.codes[dc_t][cat]), f"0{int(enc.lengths[dc_t][cat])}b"))
+            bits.append(_amplitude(diff, cat))
+            zeros = 0
+            for i in range(1, 64):
+                v = int(blk[i])
+                if v == 0:
+                    zeros += 1
+                    continue
+                while zeros > 15:
+                    bits.append(format(int(enc.codes[ac_t][0xF0]), f"0{int(enc.lengths[ac_t][0xF0])}b"))
+                    zeros -= 16
+                cat = _category(v)
+                sym = (zeros << 4) | cat
+                bits.append(format(int(enc.codes[ac_t][sym]), f"0{int(enc.lengths[ac_t][sym])}b"))
+                bits.append(_amplitude(v, cat))
+                zeros = 0
+            if zeros:
+                bits.append(format(int(enc.codes[ac_t][0]), f"0{int(enc.lengths[ac_t][0])}b"))
+    s = "".join(bits)
+    s += "0" * (-len(s) % 8)                       # fillToByteBorder pads with zero bits, BitBuffer.cpp:12-16
+    raw = bytes(int(s[i:i + 8], 2) for i in range(0, len(s), 8))
+    scan = enc.jpeg[enc.scan_offset:enc.scan_offset + enc.scan_len]
+    assert scan == raw.replace(b"\xff", b"\xff\x00")
