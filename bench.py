@@ -62,26 +62,37 @@ def measured_traffic(workload, world, frames):
     return entry["traffic_bytes_per_launch"] * entry.get("launches_per_step", 1) if entry else None
 
 
-def cpu_baseline(width, height, scheme, qt, kind):
-    """The CPU oracle (a port of the reference path) timed on a bounded crop of the workload."""
+def cpu_baseline(rgb, width, height, frames, scheme, qt, restart_interval, gpu_file):
+    """The AVX2 + OpenMP restatement of the reference path (oracle/jpeg_oracle_avx2.cpp) timed on
+    the host cores over the images the GPU encoded: the whole image, or the first frames of a
+    batch.  Its first output is compared with the GPU's file on the way (checker use only)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
-    w, h = min(width, 8192), min(height, 4096)
-    img = synth.generate(kind, w, h)
-    ri = T.padded_size(w, h, scheme)[0] // T.step_size(scheme)[0] if height > 4096 else 0
-    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
-    best = None
+    threads = int(oracle.lib_avx2().orcv_threads())
+    host = rgb.cpu().numpy()
+    per_image = width * height * 3
+    sample = min(max(frames, 1), 64)
+    best, runs, same = None, 0, None
     t_end = time.time() + 20.0
-    runs = 0
-    while runs < 2 or (time.time() < t_end and runs < 8):
-        t0 = time.perf_counter()
-        oracle.encode(img, scheme, qt, restart_interval=ri)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
+    while runs < 2 or (time.time() < t_end and runs < 5):
+        total = 0.0
+        for i in range(sample):
+            img = host[i * per_image:(i + 1) * per_image].reshape(height, width, 3)
+            tm = []
+            enc = oracle.encode(img, scheme, qt, restart_interval=restart_interval, variant="avx2", timing=tm)
+            total += tm[0]
+            if runs == 0 and i == 0:
+                same = bool(enc.jpeg == gpu_file(0))
+            del enc
+        best = total if best is None else min(best, total)
         runs += 1
-    return {"value": round(w * h / 1e6 / best, 2), "unit": "MP/s", "cores": threads, "kind": "port",
-            "sample": "%dx%d crop of the workload image, same scheme and tables, best of %d runs, OpenMP threads=%d"
-                      % (w, h, runs, threads)}
+    what = ("the whole %dx%d workload image" % (width, height)) if not frames else \
+        ("the first %d of the %d frames, one after the other" % (sample, frames))
+    return {"value": round(sample * width * height / 1e6 / best, 2), "unit": "MP/s", "cores": threads,
+            "kind": "avx2+openmp port",
+            "sample": "%s, same scheme, tables and restart interval; encode call only (pixels in host memory -> file "
+                      "in host memory), best of %d runs, OpenMP threads=%d" % (what, runs, threads),
+            "file_equals_gpu_file": same}
 
 
 def stage_rooflines(lay, images, out_bytes, kern_ms):
@@ -400,7 +411,13 @@ def main():
                          "entropy": round(float(kern_ms[2]), 4), "host_tables": round(float(kern_ms[3]), 4)},
         }
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(width, height, scheme, qt, kind)
+            def gpu_file(i):
+                if not batch:
+                    return out[:n_out].cpu().numpy().tobytes()
+                one = torch.empty(cap, dtype=torch.uint8, device=dev)
+                n = ctx.encode(rgb.data_ptr() + i * image_stride, B.RGB8, stride, params, one.data_ptr(), cap)
+                return one[:n].cpu().numpy().tobytes()
+            res["cpu_baseline"] = cpu_baseline(rgb, width, height, batch, scheme, qt, int(params.restart_interval), gpu_file)
         elif not args.no_cpu_baseline:
             res["cpu_baseline"] = None
 

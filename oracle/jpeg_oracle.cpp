@@ -380,15 +380,91 @@ std::vector<GainOp> g_gains;
 u8 g_fixedLen[4][256];
 uint16_t g_fixedCode[4][256];
 
+// An array without the zero fill of std::vector (a serial pass over every byte that also
+// takes the page faults away from the parallel loops).
+template <typename T>
+struct RawArray {
+    T* p = nullptr;
+    size_t n = 0;
+    RawArray() = default;
+    RawArray(const RawArray&) = delete;
+    RawArray& operator=(const RawArray&) = delete;
+    ~RawArray() { free(p); }
+    void resize(size_t count) {
+        free(p);
+        p = (T*)malloc((count ? count : 1) * sizeof(T));
+        if (!p) abort();
+        n = count;
+    }
+    T& operator[](size_t i) { return p[i]; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+};
+typedef RawArray<float> Plane;   // every sample is written by the de-interleave
+
 struct EncodeResult {
     std::vector<u8> jpeg;
-    std::vector<int16_t> coef[3];      // per channel, blocks in MCU order, zig-zag inside a block
+    RawArray<int16_t> coef[3];         // per channel, blocks in MCU order, zig-zag inside a block
     uint64_t hist[4][256];             // DC-Y, DC-C, AC-Y, AC-C
     HuffTable tables[4];
     size_t scanOffset, scanLen;        // entropy-coded segment inside jpeg
     int simW, simH;
     int chW[3], chH[3];
 };
+
+// Encoder::createHuffmanTable, Encoder.cpp:368-416: four tables from the four histograms.
+// Extension (sharded images): tables may come from histograms summed over all bands.
+// Extension (fixed tables, e.g. the standard ones of ITU-T T.81 Annex K.3): no table
+// optimisation at all; a symbol without a code is a caller error.
+void chooseTables(const uint64_t* histOverride, EncodeResult& res) {
+    for (int t = 0; t < 4; ++t) {
+        if (g_fixedTables) {
+            HuffTable& ht = res.tables[t];
+            for (int s = 0; s < 256; ++s) {
+                ht.len[s] = g_fixedLen[t][s];
+                ht.code[s] = g_fixedCode[t][s];
+                ht.present[s] = g_fixedLen[t][s] != 0;
+            }
+        } else {
+            buildHuffman(histOverride ? histOverride + 256 * t : res.hist[t], res.tables[t]);
+        }
+    }
+}
+
+// Everything in front of the entropy-coded segment, in the order of Encoder::serialize,
+// Encoder.cpp:439-488.
+void headerBytes(int W, int H, int headerH, const Scheme& sc, const float qt[3][64], const HuffTable tables[4],
+                 int restartInterval, std::vector<u8>& hdr) {
+    const u8 soiApp0[] = {0xff, 0xd8, 0xff, 0xe0, 0x00, 0x10, 0x4a, 0x46, 0x49, 0x46, 0x00, 0x01, 0x01,
+                          0x00, 0x00, 0x48, 0x00, 0x48, 0x00, 0x00};          // JPEGSegments.h:50-75
+    hdr.insert(hdr.end(), soiApp0, soiApp0 + sizeof soiApp0);
+    {                                                                           // JPEGSegments.h:77-100
+        const int fh = headerH > 0 ? headerH : H;   // extension: a band reports the whole image's height
+        const u8 sof[] = {0xff, 0xc0, 0x00, 0x11, 0x08, (u8)(fh >> 8), (u8)fh, (u8)(W >> 8), (u8)W, 0x03};
+        hdr.insert(hdr.end(), sof, sof + sizeof sof);
+        for (int c = 0; c < 3; ++c) {
+            hdr.push_back((u8)(c + 1));
+            hdr.push_back((u8)((sc.invW[c] << 4) | (0xf & sc.invH[c])));
+            hdr.push_back((u8)c);
+        }
+    }
+    dhtBytes(tables[0], 0, 0, hdr);    // Encoder.cpp:455-458, 476-479
+    dhtBytes(tables[1], 1, 0, hdr);
+    dhtBytes(tables[2], 0, 1, hdr);
+    dhtBytes(tables[3], 1, 1, hdr);
+    for (int c = 0; c < 3; ++c) {          // JPEGSegments.h:152-167
+        hdr.push_back(0xff); hdr.push_back(0xdb); hdr.push_back(0x00); hdr.push_back(0x43);
+        hdr.push_back((u8)c);
+        for (int i = 0; i < 64; ++i) hdr.push_back((u8)qt[c][kZigZag[i]]);
+    }
+    if (restartInterval > 0) {             // extension: DRI segment
+        const u8 dri[] = {0xff, 0xdd, 0x00, 0x04, (u8)(restartInterval >> 8), (u8)restartInterval};
+        hdr.insert(hdr.end(), dri, dri + sizeof dri);
+    }
+    const u8 sos[] = {0xff, 0xda, 0x00, 0x0c, 0x03, 0x01, 0x00, 0x02, 0x11, 0x03, 0x11, 0x00, 0x3f, 0x00};  // JPEGSegments.h:175-190
+    hdr.insert(hdr.end(), sos, sos + sizeof sos);
+}
 
 // ------------------------------------------------------------------------------------
 // The encode path, JPEG-Encoder-SIMD.cpp:397-441.
@@ -397,22 +473,6 @@ template <typename Sample>
 float normalise(Sample s);
 template <> float normalise<u8>(u8 s) { return s / 255.0f; }      // ImageLoader.cpp:190-193
 template <> float normalise<float>(float s) { return s; }        // Image::setRawPixelData takes floats
-
-// A channel plane without the zero fill of std::vector (a serial pass over 4 bytes per
-// sample that also takes the page faults away from the parallel loops).
-struct Plane {
-    float* p = nullptr;
-    Plane() = default;
-    Plane(const Plane&) = delete;
-    Plane& operator=(const Plane&) = delete;
-    ~Plane() { free(p); }
-    void resize(size_t n) {
-        p = (float*)malloc(n * sizeof(float));
-        if (!p) abort();
-    }
-    float& operator[](size_t i) { return p[i]; }
-    float* data() { return p; }
-};
 
 // ORC_TIMING=1 in the environment prints the seconds spent per stage to stderr.
 struct StageClock {
@@ -595,54 +655,13 @@ void encodeImage(const Sample* rgb, int W, int H, size_t strideSamples, const Sc
             for (u8 s : bs.acSym) res.hist[2 + t][s]++;
         }
     }
-    // Extension (sharded images): tables may come from histograms summed over all bands.
-    // Extension (fixed tables, e.g. the standard ones of ITU-T T.81 Annex K.3): no table
-    // optimisation at all; a symbol without a code is a caller error.
-    for (int t = 0; t < 4; ++t) {
-        if (g_fixedTables) {
-            HuffTable& ht = res.tables[t];
-            for (int s = 0; s < 256; ++s) {
-                ht.len[s] = g_fixedLen[t][s];
-                ht.code[s] = g_fixedCode[t][s];
-                ht.present[s] = g_fixedLen[t][s] != 0;
-            }
-        } else {
-            buildHuffman(histOverride ? histOverride + 256 * t : res.hist[t], res.tables[t]);
-        }
-    }
+    chooseTables(histOverride, res);
 
     clk.lap("histograms + tables");
     // Encoder::serialize, Encoder.cpp:439-488.
     BitSink sink;
     std::vector<u8> hdr;
-    const u8 soiApp0[] = {0xff, 0xd8, 0xff, 0xe0, 0x00, 0x10, 0x4a, 0x46, 0x49, 0x46, 0x00, 0x01, 0x01,
-                          0x00, 0x00, 0x48, 0x00, 0x48, 0x00, 0x00};          // JPEGSegments.h:50-75
-    hdr.insert(hdr.end(), soiApp0, soiApp0 + sizeof soiApp0);
-    {                                                                           // JPEGSegments.h:77-100
-        const int fh = headerH > 0 ? headerH : H;   // extension: a band reports the whole image's height
-        const u8 sof[] = {0xff, 0xc0, 0x00, 0x11, 0x08, (u8)(fh >> 8), (u8)fh, (u8)(W >> 8), (u8)W, 0x03};
-        hdr.insert(hdr.end(), sof, sof + sizeof sof);
-        for (int c = 0; c < 3; ++c) {
-            hdr.push_back((u8)(c + 1));
-            hdr.push_back((u8)((sc.invW[c] << 4) | (0xf & sc.invH[c])));
-            hdr.push_back((u8)c);
-        }
-    }
-    dhtBytes(res.tables[0], 0, 0, hdr);    // Encoder.cpp:455-458, 476-479
-    dhtBytes(res.tables[1], 1, 0, hdr);
-    dhtBytes(res.tables[2], 0, 1, hdr);
-    dhtBytes(res.tables[3], 1, 1, hdr);
-    for (int c = 0; c < 3; ++c) {          // JPEGSegments.h:152-167
-        hdr.push_back(0xff); hdr.push_back(0xdb); hdr.push_back(0x00); hdr.push_back(0x43);
-        hdr.push_back((u8)c);
-        for (int i = 0; i < 64; ++i) hdr.push_back((u8)qt[c][kZigZag[i]]);
-    }
-    if (restartInterval > 0) {             // extension: DRI segment
-        const u8 dri[] = {0xff, 0xdd, 0x00, 0x04, (u8)(restartInterval >> 8), (u8)restartInterval};
-        hdr.insert(hdr.end(), dri, dri + sizeof dri);
-    }
-    const u8 sos[] = {0xff, 0xda, 0x00, 0x0c, 0x03, 0x01, 0x00, 0x02, 0x11, 0x03, 0x11, 0x00, 0x3f, 0x00};  // JPEGSegments.h:175-190
-    hdr.insert(hdr.end(), sos, sos + sizeof sos);
+    headerBytes(W, H, headerH, sc, qt, res.tables, restartInterval, hdr);
     sink.pushBytes(hdr.data(), hdr.size());
     res.scanOffset = sink.byteLen();
 

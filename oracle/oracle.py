@@ -7,19 +7,39 @@ module; the shipped encoder never does.  The shared object is built by
 import ctypes as C
 import os
 import subprocess
+import time
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libjpeg_oracle.so")
+_SO_AVX2 = os.path.join(_HERE, "_build", "libjpeg_oracle_avx2.so")
 _lib = None
+_lib_avx2 = None
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "jpeg_oracle.cpp")
-    if force or not os.path.exists(_SO) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SO)):
+    srcs = [os.path.join(_HERE, n) for n in ("jpeg_oracle.cpp", "jpeg_oracle_avx2.cpp")]
+    stale = any(not os.path.exists(so) or any(os.path.exists(c) and os.path.getmtime(c) > os.path.getmtime(so) for c in srcs)
+                for so in (_SO, _SO_AVX2))
+    if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
+
+
+def lib_avx2():
+    """The AVX2 + OpenMP restatement (jpeg_oracle_avx2.cpp): the scalar library's interface plus
+    orcv_encode.  The CPU baseline of bench.py; checked against the scalar one by the tests."""
+    global _lib_avx2
+    if _lib_avx2 is None:
+        if not os.path.exists(_SO_AVX2):
+            build()
+        L = _bind(C.CDLL(_SO_AVX2))
+        L.orcv_encode.restype = C.c_void_p
+        L.orcv_encode.argtypes = L.orc_encode.argtypes
+        L.orcv_threads.restype = C.c_int
+        _lib_avx2 = L
+    return _lib_avx2
 
 
 def lib():
@@ -27,36 +47,39 @@ def lib():
     if _lib is None:
         if not os.path.exists(_SO):
             build()
-        L = C.CDLL(_SO)
-        L.orc_encode.restype = C.c_void_p
-        L.orc_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
-                                 C.c_int, C.c_void_p, C.c_int, C.c_int]
-        L.orc_free.argtypes = [C.c_void_p]
-        L.orc_set_fixed_tables.argtypes = [C.c_void_p, C.c_void_p]
-        L.orc_set_fixed_tables.restype = None
-        L.orc_set_channel_gains.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_set_channel_gains.restype = None
-        for name in ("orc_jpeg_size", "orc_scan_offset", "orc_scan_len"):
-            getattr(L, name).restype = C.c_int64
-            getattr(L, name).argtypes = [C.c_void_p]
-        L.orc_jpeg_copy.argtypes = [C.c_void_p, C.c_void_p]
-        L.orc_coef_count.restype = C.c_int64
-        L.orc_coef_count.argtypes = [C.c_void_p, C.c_int]
-        L.orc_coef_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        L.orc_hist_copy.argtypes = [C.c_void_p, C.c_void_p]
-        L.orc_table_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        L.orc_dims.argtypes = [C.c_void_p, C.c_void_p]
-        L.orc_constants.argtypes = [C.c_void_p]
-        L.orc_color_convert.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
-        L.orc_dct_block.argtypes = [C.c_void_p, C.c_void_p]
-        L.orc_dct_quant_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_huffman.restype = C.c_int
-        L.orc_huffman.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-        L.orc_bitbuffer_replay.restype = C.c_int64
-        L.orc_bitbuffer_replay.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64,
-                                           C.c_void_p]
-        _lib = L
+        _lib = _bind(C.CDLL(_SO))
     return _lib
+
+
+def _bind(L):
+    L.orc_encode.restype = C.c_void_p
+    L.orc_encode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
+                             C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.orc_free.argtypes = [C.c_void_p]
+    L.orc_set_fixed_tables.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_set_fixed_tables.restype = None
+    L.orc_set_channel_gains.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_set_channel_gains.restype = None
+    for name in ("orc_jpeg_size", "orc_scan_offset", "orc_scan_len"):
+        getattr(L, name).restype = C.c_int64
+        getattr(L, name).argtypes = [C.c_void_p]
+    L.orc_jpeg_copy.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_coef_count.restype = C.c_int64
+    L.orc_coef_count.argtypes = [C.c_void_p, C.c_int]
+    L.orc_coef_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_hist_copy.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_table_copy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.orc_dims.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_constants.argtypes = [C.c_void_p]
+    L.orc_color_convert.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
+    L.orc_dct_block.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_dct_quant_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_huffman.restype = C.c_int
+    L.orc_huffman.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_bitbuffer_replay.restype = C.c_int64
+    L.orc_bitbuffer_replay.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                       C.c_void_p]
+    return L
 
 
 def _p(a):
@@ -141,13 +164,13 @@ class Encoded:
 def set_fixed_tables(lengths=None, codes=None):
     """Use these Huffman tables (uint8/uint16 [4, 256]: DC-Y, DC-C, AC-Y, AC-C) for the following
     encodes instead of optimised ones; call without arguments to switch back."""
-    L = lib()
-    if lengths is None:
-        L.orc_set_fixed_tables(None, None)
-        return
-    ln = np.ascontiguousarray(lengths, np.uint8).reshape(4, 256)
-    cd = np.ascontiguousarray(codes, np.uint16).reshape(4, 256)
-    L.orc_set_fixed_tables(_p(ln), _p(cd))
+    for L in (lib(), lib_avx2()):         # each library holds its own copy of the setting
+        if lengths is None:
+            L.orc_set_fixed_tables(None, None)
+            continue
+        ln = np.ascontiguousarray(lengths, np.uint8).reshape(4, 256)
+        cd = np.ascontiguousarray(codes, np.uint16).reshape(4, 256)
+        L.orc_set_fixed_tables(_p(ln), _p(cd))
 
 
 def set_channel_gains(ops=()):
@@ -157,16 +180,20 @@ def set_channel_gains(ops=()):
     ch = np.array([o[0] for o in ops], np.int32)
     st = np.array([1 if o[2] else 0 for o in ops], np.int32)
     va = np.array([o[1] for o in ops], np.float32)
-    lib().orc_set_channel_gains(len(ops), _p(ch), _p(st), _p(va))
+    for L in (lib(), lib_avx2()):
+        L.orc_set_channel_gains(len(ops), _p(ch), _p(st), _p(va))
 
 
 def encode(rgb, scheme, qtables, restart_interval=0, pad_ones=False, stride=None, hist_override=None, rst_base=0,
-           header_height=0):
+           header_height=0, variant="scalar", timing=None):
     """rgb: uint8 or float32 array [H, W, 3]; scheme: 12 ints; qtables: float32 [3, 64].
 
     hist_override / rst_base / header_height: band of a sharded image (tables from summed
-    histograms, global RSTn numbering, whole-image height in the frame header)."""
-    L = lib()
+    histograms, global RSTn numbering, whole-image height in the frame header).
+    variant "avx2": the vectorised restatement.  timing: a list that receives the seconds the
+    encode itself took (without the copies into numpy arrays that follow it)."""
+    L = lib() if variant == "scalar" else lib_avx2()
+    fn = L.orc_encode if variant == "scalar" else L.orcv_encode
     rgb = np.asarray(rgb)
     h, w = rgb.shape[0], rgb.shape[1]
     if rgb.dtype == np.uint8:
@@ -183,8 +210,11 @@ def encode(rgb, scheme, qtables, restart_interval=0, pad_ones=False, stride=None
     ho = None
     if hist_override is not None:
         ho = np.ascontiguousarray(hist_override, np.uint64).reshape(4, 256)
-    hnd = L.orc_encode(_p(rgb), st, w, h, stride, _p(sch), _p(qt), int(restart_interval), int(pad_ones),
-                       _p(ho) if ho is not None else None, int(rst_base), int(header_height))
+    t0 = time.perf_counter()
+    hnd = fn(_p(rgb), st, w, h, stride, _p(sch), _p(qt), int(restart_interval), int(pad_ones),
+             _p(ho) if ho is not None else None, int(rst_base), int(header_height))
+    if timing is not None:
+        timing.append(time.perf_counter() - t0)
     try:
         n = L.orc_jpeg_size(hnd)
         jpeg = np.zeros(n, np.uint8)

@@ -32,9 +32,9 @@ def cases():
         yield 123, 77, "420", "annexk", "noise", ri
 
 
-def digest(w, h, scheme, tn, kind, ri):
+def digest(w, h, scheme, tn, kind, ri, variant="scalar"):
     img = synth.generate(kind, w, h, seed=w * 131 + h)
-    enc = O.encode(img, T.SCHEMES[scheme], T.NAMED_TABLES[tn], restart_interval=ri)
+    enc = O.encode(img, T.SCHEMES[scheme], T.NAMED_TABLES[tn], restart_interval=ri, variant=variant)
     hs = hashlib.sha256()
     hs.update(enc.jpeg)
     for c in range(3):

@@ -160,6 +160,42 @@ def test_oracle_output_hashes_unchanged():
     want = json.load(open(os.path.join(here, "golden", "oracle_hashes.json")))
     got = {"%dx%d_%s_%s_%s_ri%d" % c: mod.digest(*c) for c in mod.cases()}
     assert got == want
+    # the AVX2 + OpenMP restatement (bench.py's CPU baseline) writes the same files
+    got = {"%dx%d_%s_%s_%s_ri%d" % c: mod.digest(*c, variant="avx2") for c in mod.cases()}
+    assert got == want
+
+
+@pytest.mark.parametrize("scheme", sorted(T.SCHEMES))
+def test_vector_restatement_equals_scalar_one(scheme):
+    """Larger and ragged images, every scheme (those with factors other than 1 and 2 take the
+    scalar stages inside the vector library), restart intervals, one-bit padding, float pixels."""
+    for (w, h, kind, ri, pad) in [(1031, 517, "natural", 0, False), (640, 368, "noise", 7, True), (9, 5, "natural", 1, False)]:
+        img = synth.generate(kind, w, h, seed=w + h)
+        for pix in (img, (img.astype(np.float32) / np.float32(255.0))):
+            a = O.encode(pix, T.SCHEMES[scheme], T.quality_tables(90), restart_interval=ri, pad_ones=pad)
+            b = O.encode(pix, T.SCHEMES[scheme], T.quality_tables(90), restart_interval=ri, pad_ones=pad, variant="avx2")
+            assert a.jpeg == b.jpeg
+            assert all(np.array_equal(x, y) for x, y in zip(a.coef, b.coef))
+            assert np.array_equal(a.hist, b.hist)
+            assert (a.scan_offset, a.scan_len, a.channel_sizes) == (b.scan_offset, b.scan_len, b.channel_sizes)
+
+
+def test_vector_restatement_with_fixed_tables_and_band_arguments():
+    img = synth.generate("natural", 320, 200, seed=3)
+    whole = O.encode(img, T.SCHEME_420, T.quality_tables(90), restart_interval=20)
+    for variant in ("scalar", "avx2"):
+        band = O.encode(img[96:], T.SCHEME_420, T.quality_tables(90), restart_interval=20, hist_override=whole.hist, rst_base=6,
+                        header_height=200, variant=variant)
+        assert whole.scan.endswith(band.scan)
+    from jpegenc_amd import binding as B
+    lengths, codes = B.standard_huffman()
+    O.set_fixed_tables(lengths, codes)
+    try:
+        a = O.encode(img, T.SCHEME_420, T.quality_tables(90))
+        b = O.encode(img, T.SCHEME_420, T.quality_tables(90), variant="avx2")
+        assert a.jpeg == b.jpeg
+    finally:
+        O.set_fixed_tables()
 
 
 # ---- vectors assembled from literals in the reference's sources (tests/golden/make_literal_kats.py) ----
