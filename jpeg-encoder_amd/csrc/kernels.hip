@@ -8,6 +8,8 @@
 
 #include "jpegenc_hip.h"
 
+#include <cstdlib>
+
 namespace jpeghip {
 
 // ZigZag.h:10-19
@@ -617,6 +619,69 @@ __global__ __launch_bounds__(3 * k444Positions) void k_transform_444(KGeom g, co
     finish_block_staged<2>(a, rhi, rlo, stage + c * 32 * kStagePitch, coef + (m0w * 3 + c) * 64, gmask + m0w * 3 + c, 3, count);
 }
 
+// 4:4:4 with the conversion shared between the channels: one wave per workgroup, one lane per
+// block position (three blocks).  A lane converts its 64 pixels once, keeps the three
+// channels in registers and runs the transform three times.  Against the three-waves form
+// above this drops two of the three byte -> float normalisations of every pixel (a quarter
+// of that kernel's instructions) at the price of two resident waves per SIMD instead of five.
+// kHold: Cr waits in LDS (lane-interleaved 16-byte pieces: conflict free) instead of registers.
+template <bool kHold>
+__global__ __launch_bounds__(64) void k_transform_444_shared(KGeom g, const unsigned char* __restrict__ rgb,
+                                                             const float* __restrict__ qtab, int16_t* __restrict__ coef,
+                                                             unsigned char* __restrict__ gmask, u64* __restrict__ clearHist) {
+    clear_histograms(clearHist);
+    __shared__ float4 crHold[kHold ? 16 * 64 : 1];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[16 * kStagePitch];
+    const float* rhi = qtab + 192;
+    const float* rlo = qtab + 384;
+    const int lane = threadIdx.x;
+    const long long m0w = (long long)blockIdx.x * 64;
+    const long long m = m0w + lane;
+    const long long left = g.nMcu - m0w;
+    const int count = left < 64 ? (int)left : 64;
+    const long long mc = m < g.nMcu ? m : g.nMcu - 1;   // idle lanes redo the last position, store nothing
+    int mx, my;
+    rgb += locate_mcu(g, mc, mx, my);
+    const int x0 = mx * 8, y0 = my * 8;
+    const bool interior = x0 + 8 <= g.W && y0 + 8 <= g.rowsAvail;
+    u32 raw[8][6];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) load_row8(rgb, g.strideBytes, x0, y0 + r, interior, g.W, g.rowsAvail, raw[r]);
+    __builtin_amdgcn_sched_barrier(0);
+    f2 ay[32], acb[32], acr[32];   // a[rp * 8 + i]: pixel i of rows 2rp and 2rp + 1
+#pragma unroll
+    for (int rp = 0; rp < 4; ++rp) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            pixel_ycbcr_pair(raw[2 * rp], raw[2 * rp + 1], i, ay[8 * rp + i], acb[8 * rp + i], acr[8 * rp + i]);
+            // Finished here and now: left alone, the compiler moves the chroma sums behind the
+            // luma transform and keeps the normalised r, g and b of every pixel alive instead.
+            asm volatile("" : "+v"(acb[8 * rp + i]), "+v"(acr[8 * rp + i]));
+        }
+        if (kHold) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                crHold[(rp * 4 + k) * 64 + lane] = make_float4(acr[8 * rp + 2 * k].x, acr[8 * rp + 2 * k].y,
+                                                               acr[8 * rp + 2 * k + 1].x, acr[8 * rp + 2 * k + 1].y);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // row pair by row pair: bounds the live registers
+    }
+    // The three transforms one after the other.
+    finish_block_staged<4>(ay, rhi, rlo, stage, coef + m0w * 3 * 64, gmask + m0w * 3, 3, count);
+    __builtin_amdgcn_sched_barrier(0);
+    finish_block_staged<4>(acb, rhi + 64, rlo + 64, stage, coef + (m0w * 3 + 1) * 64, gmask + m0w * 3 + 1, 3, count);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kHold) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {   // the lane's own data: no barrier
+            const float4 t = crHold[j * 64 + lane];
+            acr[2 * j] = (f2){t.x, t.y};
+            acr[2 * j + 1] = (f2){t.z, t.w};
+        }
+    }
+    finish_block_staged<4>(acr, rhi + 128, rlo + 128, stage, coef + (m0w * 3 + 2) * 64, gmask + m0w * 3 + 2, 3, count);
+}
+
 // Pixel filters in front of the transform.  One thread per pixel; in place when src == dst.
 // filter < 0 only converts to float.
 __global__ __launch_bounds__(256) void k_pixel_filter(const void* __restrict__ src, int fmt, long long srcStride,
@@ -953,8 +1018,16 @@ hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qt
                            d_coef, d_gmask, d_clearHist);
     } else if (bytesAligned && scheme_is(g, 1, 1, JPEG_HIP_SUBSAMPLING)) {
         const long long grid = (g.nMcu + k444Positions - 1) / k444Positions;
-        hipLaunchKernelGGL(k_transform_444, dim3((unsigned)grid), dim3(3 * k444Positions), 0, s, g,
-                           (const unsigned char*)d_rgb, d_qtab, d_coef, d_gmask, d_clearHist);
+        static const char* form = getenv("JPEGENC_444_FORM");
+        if (form && form[0] == '3')
+            hipLaunchKernelGGL(k_transform_444, dim3((unsigned)grid), dim3(3 * k444Positions), 0, s, g,
+                               (const unsigned char*)d_rgb, d_qtab, d_coef, d_gmask, d_clearHist);
+        else if (form && form[0] == 'h')
+            hipLaunchKernelGGL(k_transform_444_shared<true>, dim3((unsigned)grid), dim3(64), 0, s, g,
+                               (const unsigned char*)d_rgb, d_qtab, d_coef, d_gmask, d_clearHist);
+        else
+            hipLaunchKernelGGL(k_transform_444_shared<false>, dim3((unsigned)grid), dim3(64), 0, s, g,
+                               (const unsigned char*)d_rgb, d_qtab, d_coef, d_gmask, d_clearHist);
     } else if (bytesAligned && rows_kernel_takes(g)) {
         const long long grid = (g.nMcu + 63) / 64;
         hipLaunchKernelGGL(k_transform_rows<false>, dim3((unsigned)grid), dim3(64 * g.bpm), 0, s, g,
