@@ -307,12 +307,13 @@ int build_tables(jpeg_hip_ctx* ctx, const uint64_t* hist, bool stageHeader = fal
 // the start of d_out (headers).
 // Launches the entropy kernels; run_entropy_wait collects their result.
 // Tile size of the bit writer on groups for a mean block length (bits), 0: the one-lane-per-block
-// writer.  A tile's bits are staged in 28 Kibit of LDS; a tile that does not fit is reported by
-// the kernel and the stage is run again one size down (16 blocks fit whatever they hold).
+// writer.  A tile's bits are staged in 22 Kibit of LDS (88 per block of the largest tile) and its
+// non-empty groups listed in room for five per block; a tile that does not fit is reported by the
+// kernel and the stage is run again one size down (16 blocks fit whatever they hold).
 int group_tile_for(int64_t avgBlockBits) {
     if (const char* forced = getenv("JPEGENC_GROUP_TILE")) return atoi(forced);   // diagnostic switch: 256, 64, 16 or 0
-    if (avgBlockBits < 0 || avgBlockBits <= 64) return 256;
-    if (avgBlockBits <= 256) return 64;
+    if (avgBlockBits < 0 || avgBlockBits <= 56) return 256;
+    if (avgBlockBits <= 224) return 64;
     return 0;
 }
 

@@ -863,6 +863,12 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
     // The runs differ by one chunk at most, so that every workgroup of the grid has work.
     const long long chFirst = chunks * blockIdx.x / gridDim.x;
     const long long chEnd = chunks * (blockIdx.x + 1) / gridDim.x;
+    if (chunks == 0 && !kBatch && blockIdx.x == 0 && threadIdx.x == 0 && hostResult) {
+        // No stream at all (a bit writer that gave up never reports the stream's end): the
+        // host still has to see why.
+        hostResult[0] = (u64)prefixLen;
+        hostResult[3] = result[1] & ~1ull;
+    }
     if (chFirst >= chEnd) return;
     u64 ffBefore = chunk_prefix(groupSum, ffCount, chFirst, lds);
     for (long long ch = chFirst; ch < chEnd; ++ch) {

@@ -20,8 +20,13 @@
 // Every wave of a workgroup works on a tile of its own; the waves share the tables only.
 
 constexpr int kGrpTileBlocks = 256;              // largest tile, blocks (four per lane)
-constexpr int kGrpMaxItems = kGrpTileBlocks * 9; // eight groups and an interval end per block
-constexpr int kGrpStageWords = 896;              // stage of one wave's tile, words (four workgroups fit a CU's LDS)
+// Room in LDS for a tile's list of items and for its bits.  Both are sized for photographic
+// content, not for the worst case (nine items and a few hundred bits per block): six workgroups
+// then fit a CU's LDS, and a wave issues an instruction only every eighth cycle or so, so the
+// kernel's speed follows the number of resident waves.  A tile that needs more is reported
+// (flag 8) and the host runs the stage again with smaller tiles; 64 blocks always fit the list.
+constexpr int kGrpMaxItems = 1278;
+constexpr int kGrpStageWords = 704;              // stage of one wave's tile, words
 constexpr int kGrpStageBits = kGrpStageWords * 32;
 constexpr int kGrpMaxFix = 24;                   // interval ends a tile can hold (intervals are >= 16 blocks)
 constexpr int kGrpMinIntervalBlocks = 16;
@@ -84,6 +89,7 @@ struct GroupTile {
     unsigned short* items;   // [kGrpMaxItems + 2]
     unsigned char* role;     // [kGrpTileBlocks]
     int nItems;
+    bool tooMany;            // the tile has more items than the list holds
 };
 
 // Lists the tile's non-empty groups in scan order and notes every block's role: bit 0 chroma,
@@ -130,6 +136,8 @@ __device__ __forceinline__ void group_index_tile(const KGeom& g, GroupTile& t) {
     const u32 incl = wave_scan_add(total);
     const u32 base = incl - total;
     t.nItems = (int)__builtin_amdgcn_readlane(incl, 63);
+    t.tooMany = t.nItems > kGrpMaxItems;
+    if (t.tooMany) t.nItems = kGrpMaxItems;   // the list stops where its room ends; the tile's output is void
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         u32 slot = base + ((counts >> (8 * i)) & 0xffu);
@@ -137,7 +145,7 @@ __device__ __forceinline__ void group_index_tile(const KGeom& g, GroupTile& t) {
         const u32 item = (u32)(lb0 + i) << 4;
 #pragma unroll
         for (int grp = 0; grp < (kIntervals ? 9 : 8); ++grp) {
-            if ((m >> grp) & 1u) t.items[slot] = (unsigned short)(item | (u32)grp);
+            if (((m >> grp) & 1u) && slot < (u32)kGrpMaxItems) t.items[slot] = (unsigned short)(item | (u32)grp);
             slot += (m >> grp) & 1u;
         }
     }
@@ -337,6 +345,7 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
     t.base = (const char*)(coef + ((long long)image * g.blocksPerImage + t.first) * 64) - (long long)kGrpBaseBlocks * 128;
     t.mask = g.groupMask + (long long)image * g.blocksPerImage + t.first;
     t.nItems = 0;
+    t.tooMany = false;
     if (t.nBlocks > 0) group_index_tile<true>(g, t);   // (a tile behind the image's last one is empty)
 
     // Position inside the tile's part of the stream, as a function of the position P at
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
     u32 runX = 0, runY = 0;
     u32 carryVal = ~0u, nFix = 0;
     u32 maxTok = 0;
-    bool overflow = false;
+    bool overflow = t.tooMany;
     GroupLoad ld;
     if (t.nItems > 0) group_issue_loads(t, 0, ld);
     for (int first = 0; first < t.nItems; first += 64) {
@@ -473,18 +482,37 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
         runX = __builtin_amdgcn_readfirstlane(runX);
         runY = __builtin_amdgcn_readfirstlane(runY);
 
-        if (f.real) {
-            if (base + len + 64u <= (u32)kGrpStageBits) {
-                if (f.zr != 0) {
-                    const u32 zl = zrlTok >> 27;
-                    for (int z = 0; z < f.zr; ++z) stage_put(st, base + (u32)z * zl, zrlTok & 0x07ffffffu, zl);
-                }
+        if (f.real && base + len + 64u > (u32)kGrpStageBits) overflow = true;
+        const bool fits = f.real && base + len + 64u <= (u32)kGrpStageBits;
+        if (__ballot(fits && len > 64u) == 0) {
+            // No lane of the chunk has more than 64 bits (photographic content at usual qualities
+            // never has): the lane strings its tokens together in a register pair and puts them into
+            // the stage with three ORs instead of two per token.
+            if (fits && len != 0) {
+                u64 acc = 0;
+                const u32 zl = zrlTok >> 27, zb = zrlTok & 0x07ffffffu;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) stage_put(st, base + off[j], tok[j] & 0x07ffffffu, tok[j] >> 27);
-                if (f.needEob) stage_put(st, base + off[8], eobTok & 0x07ffffffu, eobBits);
-            } else {
-                overflow = true;
+                for (int z = 0; z < 3; ++z)
+                    if (z < f.zr) acc = (acc << zl) | zb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = (acc << (tok[j] >> 27)) | (tok[j] & 0x07ffffffu);
+                acc = (acc << eobBits) | (f.needEob ? eobTok & 0x07ffffffu : 0u);
+                const u64 v = acc << (64u - len);   // the string, from bit 63 down
+                const u32 hi = (u32)(v >> 32), lo = (u32)v, sh = base & 31u;
+                u32* w = st + (base >> 5);
+                atomicOr(w, __builtin_amdgcn_alignbit(0u, hi, sh));
+                const u32 w1 = __builtin_amdgcn_alignbit(hi, lo, sh), w2 = __builtin_amdgcn_alignbit(lo, 0u, sh);
+                if (w1 != 0) atomicOr(w + 1, w1);
+                if (w2 != 0) atomicOr(w + 2, w2);
             }
+        } else if (fits) {
+            if (f.zr != 0) {
+                const u32 zl = zrlTok >> 27;
+                for (int z = 0; z < f.zr; ++z) stage_put(st, base + (u32)z * zl, zrlTok & 0x07ffffffu, zl);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) stage_put(st, base + off[j], tok[j] & 0x07ffffffu, tok[j] >> 27);
+            if (f.needEob) stage_put(st, base + off[8], eobTok & 0x07ffffffu, eobBits);
         }
     }
 
