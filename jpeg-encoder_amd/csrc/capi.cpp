@@ -340,6 +340,9 @@ int run_entropy_launch(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_
     // The histograms (and so streamBits) cover the whole image even when this context encodes a band.
     ctx->ws.avgBlockBits = ctx->streamBits < 0 ? -1 : ctx->streamBits / ((int64_t)ctx->geo.mcuRows * ctx->geo.mcusPerRow * ctx->geo.blocksPerMcu);
     ctx->ws.groupTile = group_tile_for(ctx->ws.avgBlockBits);
+    ctx->ws.records = ctx->recordsValid ? (const uint32_t*)ctx->records.p : nullptr;
+    ctx->ws.recCount = (const uint32_t*)ctx->recCount.p;
+    ctx->ws.recGeneration = ctx->recGeneration;
     ctx->ws.header = (const uint8_t*)ctx->tables.p + sizeof ctx->pin->tables;
     ctx->ws.headerLen = (int)prefix;
     // A header staged with the tables is fetched with them; a launch without header (a
@@ -370,8 +373,13 @@ int run_entropy_wait(jpeg_hip_ctx* ctx, int64_t* outLen) {
     // What the bit writer reports beside its bytes: 2 the chain of tiles broke, 4 the stream ran
     // past the part of the buffer that was cleared for it, 8 a tile's bits did not fit its
     // stage, 16 a symbol occurred that the tables have no code for.  4 and 8 are cured by running
-    // the stage again with a full clear / with smaller tiles.
-    for (int attempt = 0; attempt < 4 && (ctx->pin->result[3] & (4 | 8)) != 0 && (ctx->pin->result[3] & (2 | 16)) == 0; ++attempt) {
+    // the stage again with a full clear / with smaller tiles; 32: the symbol records are
+    // incomplete (a slot was too small), cured by coding from the coefficients.
+    for (int attempt = 0; attempt < 5 && (ctx->pin->result[3] & (4 | 8 | 32)) != 0 && (ctx->pin->result[3] & (2 | 16)) == 0; ++attempt) {
+        if (ctx->pin->result[3] & 32) {
+            ctx->recordsValid = false;
+            ctx->ws.records = nullptr;
+        }
         if (ctx->pin->result[3] & 4) ctx->streamBits = -1;
         if (ctx->pin->result[3] & 8) ctx->ws.groupTile = ctx->ws.groupTile > 64 ? 64 : (ctx->ws.groupTile > 16 ? 16 : 0);
         ctx->ws.pendingTables = nullptr;   // tables and header are on the device by now
@@ -380,7 +388,7 @@ int run_entropy_wait(jpeg_hip_ctx* ctx, int64_t* outLen) {
         HIP_TRY(ctx, wait_stream(ctx));
     }
     if (ctx->pin->result[3] & 16) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "the Huffman tables have no code for a symbol of this image");
-    if (ctx->pin->result[3] & (4 | 8)) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer could not place its stream");
+    if (ctx->pin->result[3] & (4 | 8 | 32)) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer could not place its stream");
     if (ctx->pin->result[2] != 0 || (ctx->pin->result[3] & 2)) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer's tiles lost their chain");
     if (ctx->pin->result[1] != 0) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "output buffer is too small for the scan");
     *outLen = (int64_t)ctx->pin->result[0];
@@ -450,6 +458,7 @@ int do_transform(jpeg_hip_ctx* ctx, int stages, bool staged = false, uint64_t* c
     mark(ctx, 1);
     ctx->transformed = true;
     ctx->stagedScanLen = -1;
+    ctx->recordsValid = false;
     // Whatever histograms the installed tables came from, they did not count these
     // coefficients: the bit count derived from them bounds nothing any more.
     ctx->streamBits = -1;
@@ -472,8 +481,25 @@ int do_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist, bool cleared = false, boo
         ex.expected = ctx->histExpected;
         ex.host = (unsigned long long*)ctx->pin->hist;
     }
-    HIP_TRY(ctx, launch_histogram(ctx->kg, (const int16_t*)ctx->coef.p, (unsigned long long*)d_hist, ctx->stream, !cleared,
-                                  toHost ? &ex : nullptr));
+    ctx->recordsValid = false;
+    if (!ctx->staticWorkspace && records_path_takes(ctx->kg)) {
+        // One pass for the histograms and for the records the bit writer will code from.
+        const size_t tiles = (size_t)records_tiles(ctx->kg);
+        HIP_TRY(ctx, ctx->records.ensure(tiles * kRecordsPerTile * sizeof(uint32_t)));
+        if (ctx->recCount.cap < (tiles + 1) * sizeof(uint32_t)) {
+            HIP_TRY(ctx, ctx->recCount.ensure((tiles + 1) * sizeof(uint32_t)));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->recCount.p, 0, sizeof(uint32_t), ctx->stream));   // the overflow word
+            ctx->recGeneration = 0;
+        }
+        ++ctx->recGeneration;
+        HIP_TRY(ctx, launch_symbol_records(ctx->kg, (const int16_t*)ctx->coef.p, (unsigned long long*)d_hist, ctx->stream, !cleared,
+                                           toHost ? &ex : nullptr, (uint32_t*)ctx->records.p, (uint32_t*)ctx->recCount.p,
+                                           ctx->recGeneration));
+        ctx->recordsValid = true;
+    } else {
+        HIP_TRY(ctx, launch_histogram(ctx->kg, (const int16_t*)ctx->coef.p, (unsigned long long*)d_hist, ctx->stream, !cleared,
+                                      toHost ? &ex : nullptr));
+    }
     if (toHost) {
         ctx->histExpected = ex.expected;
         ctx->histOnHost = true;
@@ -545,7 +571,7 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->gmask, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->groupSum, &ctx->result,
                       &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart,
                       &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum, &ctx->pixelsF, &ctx->pipeIn[0], &ctx->pipeIn[1],
-                      &ctx->pipeOut, &ctx->histDone, &ctx->gather, &ctx->repacked};
+                      &ctx->pipeOut, &ctx->histDone, &ctx->gather, &ctx->repacked, &ctx->records, &ctx->recCount};
     delete ctx->decoded;
     delete ctx->workers;
     delete ctx->packers;

@@ -225,6 +225,9 @@ struct jpeg_hip_ctx {
     jpeghip::HostBuf uploadStage[2];                      // pinned blocks jpeg_hip_upload_pixels sends its pieces from
     hipEvent_t uploadEvent[2] = {nullptr, nullptr};
     jpeghip::DevBuf gather;                               // one channel's coefficients, contiguous (jpeg_hip_get_coefficients)
+    jpeghip::DevBuf records, recCount;                    // symbol records of the current coefficients (launch_symbol_records)
+    uint32_t recGeneration = 0;                  // number of the last launch that wrote them
+    bool recordsValid = false;                   // they belong to the current coefficients
     jpeghip::DevBuf histDone;                             // counter of the histogram kernel's host export
     unsigned long long histExpected = 0;         // value of that counter once every launch so far has finished
     bool histOnHost = false;                     // pin->hist holds the current band's histograms as counted

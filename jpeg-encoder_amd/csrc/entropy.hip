@@ -497,6 +497,42 @@ static long long group_tiles_per_image(long long blocksPerImage, int tileBlocks)
     return ((blocksPerImage + tileBlocks - 1) / tileBlocks + 3) / 4 * 4;
 }
 
+#include "entropy_records.h"
+static_assert(kRecPerTile == kRecordsPerTile, "the host sizes the record slots");
+
+static long long group_min_blocks() {
+    // (Diagnostic switch JPEGENC_GROUP_MIN_BLOCKS: another threshold, e.g. 0 to test it on small images.)
+    const char* minEnv = getenv("JPEGENC_GROUP_MIN_BLOCKS");
+    return minEnv ? atoll(minEnv) : kGrpMinBlocks;
+}
+
+// The two-pass form takes single images that are large enough for the kernels on groups, with
+// restart intervals of sixteen blocks and more (or none).  (Diagnostic switch JPEGENC_NO_RECORDS=1:
+// never.)
+bool records_path_takes(const KGeom& g) {
+    static const bool off = getenv("JPEGENC_NO_RECORDS") != nullptr && getenv("JPEGENC_NO_RECORDS")[0] == '1';
+    return !off && !old_entropy_kernels() && g.batch == 1 && g.totalBlocks >= group_min_blocks() &&
+           (g.intervals == 1 || g.mcusPerInterval * g.bpm >= kGrpMinIntervalBlocks) && g.intervals <= kRecMaxIntervals &&
+           g.groupMask != nullptr;
+}
+
+long long records_tiles(const KGeom& g) { return group_tiles_per_image(g.blocksPerImage, kGrpTileBlocks); }
+
+hipError_t launch_symbol_records(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, bool clear,
+                                 HistogramExport* ex, u32* d_records, u32* d_recCount, u32 generation) {
+    if (clear) {
+        const hipError_t e = launch_clear_histograms(d_hist, 1, s);
+        if (e != hipSuccess) return e;
+    }
+    const long long quads = records_tiles(g) / 4;
+    const long long grid = quads < 2048 ? quads : 2048;
+    HistogramExport none = {nullptr, 0, nullptr};
+    if (ex != nullptr) ex->expected += (unsigned long long)grid;   // what the counter reads when all are done
+    hipLaunchKernelGGL(k_symbol_records, dim3((unsigned)grid), dim3(256), 0, s, g, d_coef, d_hist, ex != nullptr ? *ex : none,
+                       d_records, d_recCount + 1, d_recCount, generation);
+    return hipGetLastError();
+}
+
 // kPrivate: blocks are short on average (photographic content), so the first walk keeps
 // each block's bits in a few private LDS words and the second walk is a copy; otherwise the
 // first walk only measures and every block is walked twice.
@@ -1029,12 +1065,13 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     // It pays from a few hundred thousand blocks on; below, a wave's walk through a whole tile
     // is a longer chain than the image has work to hide (1080p: 37 -> 44 us).
     // (Diagnostic switch JPEGENC_GROUP_MIN_BLOCKS: another threshold, e.g. 0 to test it on small images.)
-    const char* minEnv = getenv("JPEGENC_GROUP_MIN_BLOCKS");
-    const long long minBlocks = minEnv ? atoll(minEnv) : kGrpMinBlocks;
+    const long long minBlocks = group_min_blocks();
+    const bool fromRecords = ws.records != nullptr && bo == nullptr;
     const bool groups = ws.groupTile > 0 && !old_entropy_kernels() && g.totalBlocks >= minBlocks &&
                         (g.intervals == g.batch || g.mcusPerInterval * g.bpm >= kGrpMinIntervalBlocks);
-    const long long tilesPerImage = groups ? group_tiles_per_image(g.blocksPerImage, ws.groupTile)
-                                           : (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
+    const long long tilesPerImage = fromRecords ? records_tiles(g)
+                                    : groups    ? group_tiles_per_image(g.blocksPerImage, ws.groupTile)
+                                                : (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
     const long long tileCount = tilesPerImage * g.batch;
     // The bit writer ORs into the stream, so the part it can reach starts out as zeros.
     long long zero = ws.streamBound < 0 ? ws.unstuffedCap : (ws.streamBound + kStuffChunk + 63) / 16 * 16;
@@ -1049,7 +1086,15 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
                        bo ? nullptr : ws.pendingTables, const_cast<u32*>(d_tables));
     // Long blocks (noise, q=100) do not fit the private words; unknown lengths count as short.
     const bool shortBlocks = ws.avgBlockBits <= 128;
-    if (groups)
+    if (fromRecords) {
+        hipLaunchKernelGGL(k_record_lengths, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, ws.records, ws.recCount + 1,
+                           ws.recCount, ws.recGeneration, d_tables, ws.tileState, ws.result);
+        hipLaunchKernelGGL(k_tile_positions, dim3(1), dim3(1024), 0, s, g, ws.tileState, (u32)tileCount);
+        hipLaunchKernelGGL(k_emit_records, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, ws.records, ws.recCount + 1,
+                           ws.recCount, ws.recGeneration, d_tables, ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed,
+                           zero);
+    }
+    else if (groups)
         hipLaunchKernelGGL(k_encode_groups, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, d_coef, d_tables, ws.tileState,
                            ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero);
     else if (shortBlocks)

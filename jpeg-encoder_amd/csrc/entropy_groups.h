@@ -86,7 +86,8 @@ struct GroupTile {
     const unsigned char* mask;   // group masks of the tile's blocks
     u32 first;               // first block of the tile inside its image
     int nBlocks;
-    unsigned short* items;   // [kGrpMaxItems + 2]
+    unsigned short* items;   // [cap + 2]
+    int cap;                 // items the list has room for
     unsigned char* role;     // [kGrpTileBlocks]
     int nItems;
     bool tooMany;            // the tile has more items than the list holds
@@ -136,8 +137,8 @@ __device__ __forceinline__ void group_index_tile(const KGeom& g, GroupTile& t) {
     const u32 incl = wave_scan_add(total);
     const u32 base = incl - total;
     t.nItems = (int)__builtin_amdgcn_readlane(incl, 63);
-    t.tooMany = t.nItems > kGrpMaxItems;
-    if (t.tooMany) t.nItems = kGrpMaxItems;   // the list stops where its room ends; the tile's output is void
+    t.tooMany = t.nItems > t.cap;
+    if (t.tooMany) t.nItems = t.cap;   // the list stops where its room ends; the tile's output is void
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         u32 slot = base + ((counts >> (8 * i)) & 0xffu);
@@ -145,7 +146,7 @@ __device__ __forceinline__ void group_index_tile(const KGeom& g, GroupTile& t) {
         const u32 item = (u32)(lb0 + i) << 4;
 #pragma unroll
         for (int grp = 0; grp < (kIntervals ? 9 : 8); ++grp) {
-            if (((m >> grp) & 1u) && slot < (u32)kGrpMaxItems) t.items[slot] = (unsigned short)(item | (u32)grp);
+            if (((m >> grp) & 1u) && slot < (u32)t.cap) t.items[slot] = (unsigned short)(item | (u32)grp);
             slot += (m >> grp) & 1u;
         }
     }
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
 
     GroupTile t;
     t.items = items[wave];
+    t.cap = kGrpMaxItems;
     t.role = roleTab[wave];
     u32* st = stage[wave];
     const u32 tileInImage = tile - image * tilesPerImage;
