@@ -16,10 +16,11 @@
 // bits 31..16 the amplitude bits; or bit 10 set: a restart interval ends here, bits 31..11 hold
 // its number inside the band.
 
-constexpr int kRecPerTile = 4096;        // records a tile's slot holds (16 per block; photographic content has 8)
+constexpr int kRecPerTile = 6144;        // records a tile's slot holds (24 per block; photographic content has 8 to 12)
 constexpr int kRecMaxItems = kGrpTileBlocks * 9;
 constexpr u32 kRecEnd = 0x400u;
 constexpr int kRecMaxIntervals = 1 << 21;
+constexpr int kRecStageWords = 512;      // records of one step gathered in LDS so that they leave in whole lines (a step has 64 to 832)
 constexpr int kEmitStageWords = 240;     // 256 records of 27 bits, the padding and markers of eight interval ends, slack
 
 // ---- pass 1: symbols --------------------------------------------------------------------------
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(256) void k_symbol_records(KGeom g, const int16_t* 
     __shared__ u32 lh[4 * 256];   // DC-Y, DC-C, AC-Y, AC-C (Encoder.cpp:368-416)
     __shared__ unsigned short items[4][kRecMaxItems + 2];
     __shared__ unsigned char roleTab[4][kGrpTileBlocks];
+    __shared__ u32 outStage[4][kRecStageWords];
     __shared__ bool lastOne;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -84,43 +86,54 @@ __global__ __launch_bounds__(256) void k_symbol_records(KGeom g, const int16_t* 
             const u32 mine = f.boundary ? 1u : (f.real ? zr + (u32)__popc(f.mm & 0xffu) + (f.needEob ? 1u : 0u) : 0u);
             const u32 incl = wave_scan_add(mine);
             const u32 total = __builtin_amdgcn_readlane(incl, 63);
-            u32 at = written + incl - mine;
-            if (written + total > (u32)kRecPerTile) {
-                overflow = true;   // the slot is full: count on, write nothing more
-                at = (u32)kRecPerTile;
-            }
-            written += total;
-            if (f.boundary && at < (u32)kRecPerTile) {
-                const u32 bl = t.first + f.lb;
-                const u32 iv = (bl / (u32)g.bpm) / (u32)g.mcusPerInterval;
-                out[at] = kRecEnd | (iv << 11);
-            }
-            if (f.real) {
-                if (zr != 0) {
-                    atomicAdd(&lh[(acSel | 0xF0u)], zr);
-                    for (u32 z = 0; z < zr; ++z)
-                        if (at + z < (u32)kRecPerTile) out[at + z] = acSel | 0xF0u;
+            if (written + total > (u32)kRecPerTile) overflow = true;   // the slot is full: what does not fit is dropped
+            const u32 at = incl - mine;
+            // The step's records are gathered in LDS and leave as consecutive words, kRecStageWords
+            // at a time (one round, except for steps of very busy groups).
+            for (u32 part = 0; part < total; part += (u32)kRecStageWords) {
+                const u32 lim = total - part < (u32)kRecStageWords ? total - part : (u32)kRecStageWords;
+                u32* dst = outStage[wave];
+                const bool count = part == 0;
+                if (f.boundary && at - part < lim) {
+                    const u32 bl = t.first + f.lb;
+                    const u32 iv = (bl / (u32)g.bpm) / (u32)g.mcusPerInterval;
+                    dst[at - part] = kRecEnd | (iv << 11);
                 }
-                u32 slot = at + zr;
+                if (f.real) {
+                    if (zr != 0) {
+                        if (count) atomicAdd(&lh[(acSel | 0xF0u)], zr);
+                        for (u32 z = 0; z < zr; ++z)
+                            if (at + z - part < lim) dst[at + z - part] = acSel | 0xF0u;
+                    }
+                    u32 slot = at + zr - part;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int v = (int)(short)(f.d[j >> 1] >> (16 * (j & 1)));
-                    const u32 cat = (u32)__builtin_amdgcn_frexp_expf((float)v);   // bits of |v|, 0 for 0
-                    const u32 run = (u32)__builtin_clz(f.X << (16 - j));
-                    u32 key = acSel | ((run & 15u) << 4) | cat;
-                    if (j == 0 && f.isK0) key = (f.chroma << 8) | cat;
-                    const u32 rec = (__builtin_amdgcn_ubfe(amp[j >> 1], 16 * (j & 1), cat) << 16) | key;
-                    if ((f.mm >> j) & 1u) {
-                        atomicAdd(&lh[key], 1u);
-                        if (slot < (u32)kRecPerTile) out[slot] = rec;
-                        ++slot;
+                    for (int j = 0; j < 8; ++j) {
+                        const int v = (int)(short)(f.d[j >> 1] >> (16 * (j & 1)));
+                        const u32 cat = (u32)__builtin_amdgcn_frexp_expf((float)v);   // bits of |v|, 0 for 0
+                        const u32 run = (u32)__builtin_clz(f.X << (16 - j));
+                        u32 key = acSel | ((run & 15u) << 4) | cat;
+                        if (j == 0 && f.isK0) key = (f.chroma << 8) | cat;
+                        const u32 rec = (__builtin_amdgcn_ubfe(amp[j >> 1], 16 * (j & 1), cat) << 16) | key;
+                        if ((f.mm >> j) & 1u) {
+                            if (count) atomicAdd(&lh[key], 1u);
+                            if (slot < lim) dst[slot] = rec;
+                            ++slot;
+                        }
+                    }
+                    if (f.needEob) {
+                        if (count) atomicAdd(&lh[acSel], 1u);
+                        if (slot < lim) dst[slot] = acSel;
                     }
                 }
-                if (f.needEob) {
-                    atomicAdd(&lh[acSel], 1u);
-                    if (slot < (u32)kRecPerTile) out[slot] = acSel;
-                }
+                // The same wave wrote and reads: only the LDS counter has to drain.
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                for (u32 i = lane; i < lim; i += 64)
+                    if (written + part + i < (u32)kRecPerTile) out[written + part + i] = dst[i];
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
             }
+            written += total;
         }
         if (lane == 0) recCount[tile] = written < (u32)kRecPerTile ? written : (u32)kRecPerTile;
     }
@@ -160,11 +173,16 @@ struct RecordQuad {
     u32 iv;
 };
 
-__device__ __forceinline__ void decode_quad(const u32* __restrict__ rec, u32 first, u32 n, const u32* tab, RecordQuad& q) {
-    const int lane = threadIdx.x & 63;
-    const u32 i0 = first + 4u * (u32)lane;
+// The four records of a lane in the step that starts at record `first`; records behind the n-th read as 0.
+__device__ __forceinline__ uint4 load_quad(const u32* __restrict__ rec, u32 first, u32 n) {
+    const u32 i0 = first + 4u * (u32)(threadIdx.x & 63);
     uint4 r = make_uint4(0, 0, 0, 0);
     if (i0 < n) r = *(const uint4*)(rec + i0);
+    return r;
+}
+
+__device__ __forceinline__ void decode_quad(uint4 r, u32 first, u32 n, const u32* tab, RecordQuad& q) {
+    const u32 i0 = first + 4u * (u32)(threadIdx.x & 63);
     const u32 w[4] = {r.x, r.y, r.z, r.w};
     q.end = 4;
     q.iv = 0;
@@ -182,6 +200,10 @@ __device__ __forceinline__ void decode_quad(const u32* __restrict__ rec, u32 fir
         q.len[k] = sym ? e >> 27 : 0u;
     }
 }
+
+// A tile's records are read four steps ahead: a wave that waits for every kilobyte before it asks
+// for the next spends its life waiting.
+constexpr int kRecAhead = 4;
 
 // Token templates of one table set in LDS: the code shifted left by the category, so that the
 // amplitude bits can be ORed in, and the total number of bits in bits 31..27 (entries of
@@ -246,9 +268,15 @@ __global__ __launch_bounds__(256) void k_record_lengths(KGeom g, const u32* __re
     const u32* rec = records + (size_t)tile * kRecPerTile;
     PosSummary run = {0u, 0u};
     u32 maxLen = 0;
+    uint4 ahead[kRecAhead];
+#pragma unroll
+    for (int a = 0; a < kRecAhead; ++a) ahead[a] = load_quad(rec, 256u * a, n);
     for (u32 first = 0; first < n; first += 256) {
         RecordQuad q;
-        decode_quad(rec, first, n, tab, q);
+        decode_quad(ahead[0], first, n, tab, q);
+#pragma unroll
+        for (int a = 0; a + 1 < kRecAhead; ++a) ahead[a] = ahead[a + 1];
+        ahead[kRecAhead - 1] = load_quad(rec, first + 256u * kRecAhead, n);
         const u32 m01 = q.len[0] > q.len[1] ? q.len[0] : q.len[1], m23 = q.len[2] > q.len[3] ? q.len[2] : q.len[3];
         maxLen = maxLen > m01 ? maxLen : m01;
         maxLen = maxLen > m23 ? maxLen : m23;
@@ -264,15 +292,31 @@ __global__ __launch_bounds__(256) void k_record_lengths(KGeom g, const u32* __re
     if (__ballot(maxLen >= 31u) != 0 && lane == 0) atomicOr((unsigned long long*)&result[1], 16ull);   // a symbol without a code
 }
 
-// Pass 2b: summaries to start positions, in place.  One workgroup; every thread takes a run
-// of consecutive tiles.
-__global__ __launch_bounds__(1024) void k_tile_positions(KGeom g, u64* __restrict__ summary, u32 tiles) {
+// Pass 2b: summaries to start positions in two small steps.  k_group_positions: one wave per
+// run of 64 tiles replaces each tile's summary by the summary of the tiles in front of it inside
+// the run, and notes the run's own summary.  k_run_positions: one workgroup turns the runs'
+// summaries into the positions at which the runs start.  A tile then starts at
+// pos_apply(summary[tile], runStart[tile / 64]).
+__global__ __launch_bounds__(64) void k_group_positions(u64* __restrict__ summary, u64* __restrict__ runSummary, u32 tiles) {
+    const int lane = threadIdx.x;
+    const u32 t = blockIdx.x * 64u + (u32)lane;
+    const u64 v = t < tiles ? summary[t] : 0ull;
+    const PosSummary inc = wave_scan_summary(PosSummary{(u32)(v >> 32), (u32)v});
+    PosSummary excl;
+    excl.x = __shfl_up(inc.x, 1, 64);
+    excl.y = __shfl_up(inc.y, 1, 64);
+    if (lane == 0) excl.x = excl.y = 0;
+    if (t < tiles) summary[t] = ((u64)excl.x << 32) | excl.y;
+    if (lane == 63) runSummary[blockIdx.x] = ((u64)inc.x << 32) | inc.y;
+}
+
+__global__ __launch_bounds__(1024) void k_run_positions(KGeom g, u64* __restrict__ runSummary, u32 runs) {
     __shared__ PosSummary part[1024];
-    const u32 per = (tiles + 1023u) / 1024u;
-    const u32 t0 = threadIdx.x * per, t1 = t0 + per < tiles ? t0 + per : tiles;
+    const u32 per = (runs + 1023u) / 1024u;   // 1 up to 65536 tiles
+    const u32 t0 = threadIdx.x * per, t1 = t0 + per < runs ? t0 + per : runs;
     PosSummary mine = {0u, 0u};
     for (u32 t = t0; t < t1; ++t) {
-        const u64 v = summary[t];
+        const u64 v = runSummary[t];
         mine = pos_combine(mine, PosSummary{(u32)(v >> 32), (u32)v});
     }
     part[threadIdx.x] = mine;
@@ -288,19 +332,19 @@ __global__ __launch_bounds__(1024) void k_tile_positions(KGeom g, u64* __restric
     if (threadIdx.x > 0) before = part[threadIdx.x - 1];
     const u64 p0 = 8ull * (u64)interval_marker_bytes(g, 0);
     for (u32 t = t0; t < t1; ++t) {
-        const u64 v = summary[t];
-        summary[t] = pos_apply(before, p0);
+        const u64 v = runSummary[t];
+        runSummary[t] = pos_apply(before, p0);
         before = pos_combine(before, PosSummary{(u32)(v >> 32), (u32)v});
     }
 }
 
-// Pass 2c: the bits, at their final positions (position[tile]: bit at which the tile starts).
+// Pass 2c: the bits, at their final positions (see k_group_positions for where a tile starts).
 // A step's bits are gathered in the stage (word 0 is the stream word the step starts in) and
 // leave as whole words.
 __global__ __launch_bounds__(256) void k_emit_records(KGeom g, const u32* __restrict__ records, const u32* __restrict__ recCount,
                                                       const u32* __restrict__ recFlag, u32 generation,
-                                                      const u32* __restrict__ tables, const u64* __restrict__ position,
-                                                      u64* __restrict__ ivOff, u64* __restrict__ result, u32* __restrict__ words,
+                                                      const u32* __restrict__ tables, const u64* __restrict__ summary,
+                                                      const u64* __restrict__ runStart, u64* __restrict__ ivOff, u64* __restrict__ result, u32* __restrict__ words,
                                                       long long zeroedBytes) {
     __shared__ u32 tab[4 * 256];
     __shared__ u32 stage[4][kEmitStageWords];
@@ -314,10 +358,17 @@ __global__ __launch_bounds__(256) void k_emit_records(KGeom g, const u32* __rest
     u32* st = stage[wave];
     const u32 n = recCount[tile];
     const u32* rec = records + (size_t)tile * kRecPerTile;
-    u64 pos = position[tile];   // position of the step's first bit
+    const u64 inRun = summary[tile];
+    u64 pos = pos_apply(PosSummary{(u32)(inRun >> 32), (u32)inRun}, runStart[tile >> 6]);   // position of the step's first bit
+    uint4 ahead[kRecAhead];
+#pragma unroll
+    for (int a = 0; a < kRecAhead; ++a) ahead[a] = load_quad(rec, 256u * a, n);
     for (u32 first = 0; first < n; first += 256) {
         RecordQuad q;
-        decode_quad(rec, first, n, tab, q);
+        decode_quad(ahead[0], first, n, tab, q);
+#pragma unroll
+        for (int a = 0; a + 1 < kRecAhead; ++a) ahead[a] = ahead[a + 1];
+        ahead[kRecAhead - 1] = load_quad(rec, first + 256u * kRecAhead, n);
         const u64 origin = pos & ~31ull;
         const u64 ends = __ballot(q.end != 4);
         const u32 len = q.len[0] + q.len[1] + q.len[2] + q.len[3];
@@ -379,20 +430,29 @@ __global__ __launch_bounds__(256) void k_emit_records(KGeom g, const u32* __rest
         // The same wave wrote and reads: only the LDS counter has to drain.
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        const u32 nWords = (u32)(((next + 31) >> 5) - (origin >> 5));
-        for (u32 i = lane; i < nWords; i += 64) {
+        // Whole words leave; a last, incomplete one stays behind as word 0 of the next step.  Only
+        // the tile's first word can be shared with another tile (an atomic at device scope takes
+        // microseconds: one per tile and end, not per step).
+        const u32 nFull = (u32)((next >> 5) - (origin >> 5));
+        for (u32 i = lane; i < nFull; i += 64) {
             const u32 v = st[i];
             if (v != 0) {
                 st[i] = 0;
                 const u32 o = __builtin_bswap32(v);
-                if (i == 0 || i == nWords - 1) atomicOr(&words[(origin >> 5) + i], o);   // shared with the neighbours
+                if (i == 0 && first == 0) atomicOr(&words[(origin >> 5) + i], o);
                 else words[(origin >> 5) + i] = o;
             }
+        }
+        if (nFull != 0 && lane == 0) {
+            const u32 rest = st[nFull];
+            st[nFull] = 0;
+            st[0] = rest;
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         pos = next;
     }
+    if (lane == 0 && n != 0 && (pos & 31) != 0 && st[0] != 0) atomicOr(&words[pos >> 5], __builtin_bswap32(st[0]));
     if (tile == 0 && lane == 0) {
         ivOff[0] = 0;
         if (interval_marker_bytes(g, 0) != 0) atomicOr(&words[0], __builtin_bswap32((0xffd0u + (u32)((g.firstInterval - 1) & 7)) << 16));

@@ -132,7 +132,7 @@ hipError_t launch_clear_histograms(unsigned long long* d_hist, int images, hipSt
 // Histograms and symbol records in one pass (single images of a few hundred thousand blocks and
 // more; records_path_takes says which).  d_records: records_tiles(g) slots of kRecordsPerTile
 // words; d_recCount: 1 + records_tiles(g) words, the first one zero before the first launch.
-constexpr int kRecordsPerTile = 4096;
+constexpr int kRecordsPerTile = 6144;
 bool records_path_takes(const KGeom& g);
 long long records_tiles(const KGeom& g);
 hipError_t launch_symbol_records(const KGeom& g, const int16_t* d_coef, unsigned long long* d_hist, hipStream_t s, bool clear,
