@@ -621,16 +621,16 @@ __global__ __launch_bounds__(3 * k444Positions) void k_transform_444(KGeom g, co
 
 // 4:4:4 with the conversion shared between the channels: one wave per workgroup, one lane per
 // block position (three blocks).  A lane converts its 64 pixels once, keeps the three
-// channels in registers and runs the transform three times.  Against the three-waves form
-// above this drops two of the three byte -> float normalisations of every pixel (a quarter
-// of that kernel's instructions) at the price of two resident waves per SIMD instead of five.
-// kHold: Cr waits in LDS (lane-interleaved 16-byte pieces: conflict free) instead of registers.
-template <bool kHold>
+// channels in registers (214 of them: two waves per SIMD) and runs the transform three times.
+// Against the three-waves form above this drops two of the three byte -> float normalisations
+// of every pixel, a quarter of that kernel's instructions, and has a third of its waves: a
+// wave issues an instruction only every eighth cycle or so, so a SIMD wants four and more
+// resident waves to fill its pipeline, which this form cannot give it.  Measured: 3840 x 2160
+// both 23 us, 8192 x 8192 132 against 139 us; small images need the other form's many waves.
 __global__ __launch_bounds__(64) void k_transform_444_shared(KGeom g, const unsigned char* __restrict__ rgb,
                                                              const float* __restrict__ qtab, int16_t* __restrict__ coef,
                                                              unsigned char* __restrict__ gmask, u64* __restrict__ clearHist) {
     clear_histograms(clearHist);
-    __shared__ float4 crHold[kHold ? 16 * 64 : 1];
     __shared__ __attribute__((aligned(16))) unsigned char stage[16 * kStagePitch];
     const float* rhi = qtab + 192;
     const float* rlo = qtab + 384;
@@ -655,14 +655,9 @@ __global__ __launch_bounds__(64) void k_transform_444_shared(KGeom g, const unsi
         for (int i = 0; i < 8; ++i) {
             pixel_ycbcr_pair(raw[2 * rp], raw[2 * rp + 1], i, ay[8 * rp + i], acb[8 * rp + i], acr[8 * rp + i]);
             // Finished here and now: left alone, the compiler moves the chroma sums behind the
-            // luma transform and keeps the normalised r, g and b of every pixel alive instead.
+            // luma transform and keeps the normalised r, g and b of every pixel alive instead
+            // (278 registers, one wave per SIMD).
             asm volatile("" : "+v"(acb[8 * rp + i]), "+v"(acr[8 * rp + i]));
-        }
-        if (kHold) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                crHold[(rp * 4 + k) * 64 + lane] = make_float4(acr[8 * rp + 2 * k].x, acr[8 * rp + 2 * k].y,
-                                                               acr[8 * rp + 2 * k + 1].x, acr[8 * rp + 2 * k + 1].y);
         }
         __builtin_amdgcn_sched_barrier(0);   // row pair by row pair: bounds the live registers
     }
@@ -671,14 +666,6 @@ __global__ __launch_bounds__(64) void k_transform_444_shared(KGeom g, const unsi
     __builtin_amdgcn_sched_barrier(0);
     finish_block_staged<4>(acb, rhi + 64, rlo + 64, stage, coef + (m0w * 3 + 1) * 64, gmask + m0w * 3 + 1, 3, count);
     __builtin_amdgcn_sched_barrier(0);
-    if (kHold) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {   // the lane's own data: no barrier
-            const float4 t = crHold[j * 64 + lane];
-            acr[2 * j] = (f2){t.x, t.y};
-            acr[2 * j + 1] = (f2){t.z, t.w};
-        }
-    }
     finish_block_staged<4>(acr, rhi + 128, rlo + 128, stage, coef + (m0w * 3 + 2) * 64, gmask + m0w * 3 + 2, 3, count);
 }
 
@@ -1018,15 +1005,15 @@ hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qt
                            d_coef, d_gmask, d_clearHist);
     } else if (bytesAligned && scheme_is(g, 1, 1, JPEG_HIP_SUBSAMPLING)) {
         const long long grid = (g.nMcu + k444Positions - 1) / k444Positions;
+        // One wave per 64 block positions from about a hundred thousand positions on (see
+        // k_transform_444_shared); diagnostic switch JPEGENC_444_FORM=3 / 1: always three waves / one.
         static const char* form = getenv("JPEGENC_444_FORM");
-        if (form && form[0] == '3')
-            hipLaunchKernelGGL(k_transform_444, dim3((unsigned)grid), dim3(3 * k444Positions), 0, s, g,
-                               (const unsigned char*)d_rgb, d_qtab, d_coef, d_gmask, d_clearHist);
-        else if (form && form[0] == 'h')
-            hipLaunchKernelGGL(k_transform_444_shared<true>, dim3((unsigned)grid), dim3(64), 0, s, g,
-                               (const unsigned char*)d_rgb, d_qtab, d_coef, d_gmask, d_clearHist);
+        const bool shared = form ? form[0] == '1' : g.nMcu >= 100000;
+        if (shared)
+            hipLaunchKernelGGL(k_transform_444_shared, dim3((unsigned)grid), dim3(64), 0, s, g, (const unsigned char*)d_rgb,
+                               d_qtab, d_coef, d_gmask, d_clearHist);
         else
-            hipLaunchKernelGGL(k_transform_444_shared<false>, dim3((unsigned)grid), dim3(64), 0, s, g,
+            hipLaunchKernelGGL(k_transform_444, dim3((unsigned)grid), dim3(3 * k444Positions), 0, s, g,
                                (const unsigned char*)d_rgb, d_qtab, d_coef, d_gmask, d_clearHist);
     } else if (bytesAligned && rows_kernel_takes(g)) {
         const long long grid = (g.nMcu + 63) / 64;

@@ -2,7 +2,7 @@
 # bash scripts/ab_444.sh   (on the GPU box)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for FORM in 3 r; do
+for FORM in 3 1; do
   export JPEGENC_444_FORM=$FORM
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab444_$FORM -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --pipelined-steps 0 --workload 4k_444_q90 > gpurun_out/ab444_$FORM.log 2>&1
   python3 - <<PY
