@@ -181,17 +181,20 @@ int ensure_workspace(jpeg_hip_ctx* ctx, int images = 1) {
     // With borrowed buffers the unstuffed stream gets what its slice holds, not the worst case.
     const WorkspaceSizes sz = workspace_sizes(ctx->geo, images, ctx->staticWorkspace ? (int64_t)ctx->unstuffed.cap : -1);
     const int64_t unstuffedCap = sz.unstuffedCap, maxChunks = sz.maxChunks;
+    // A batch pass runs its entropy stage in two halves, each in a slice of these buffers: two
+    // slices need a little more than one whole (constants of the size formulas count twice).
+    const size_t slack = images > 1 ? 16384 : 0;
     HIP_TRY(ctx, ctx->coef.ensure(sz.coef));
     HIP_TRY(ctx, ctx->gmask.ensure(sz.gmask));
     HIP_TRY(ctx, ctx->qtab.ensure(sz.qtab));
     HIP_TRY(ctx, ctx->hist.ensure(sz.hist));
     HIP_TRY(ctx, ctx->tables.ensure(sz.tables));
-    HIP_TRY(ctx, ctx->ivOff.ensure(sz.ivOff));
-    HIP_TRY(ctx, ctx->ffCount.ensure(sz.ffCount));
-    HIP_TRY(ctx, ctx->groupSum.ensure(sz.groupSum));
-    HIP_TRY(ctx, ctx->result.ensure(sz.result));
-    HIP_TRY(ctx, ctx->unstuffed.ensure(sz.unstuffed));
-    HIP_TRY(ctx, ctx->tileState.ensure(sz.tileState));
+    HIP_TRY(ctx, ctx->ivOff.ensure(sz.ivOff + slack));
+    HIP_TRY(ctx, ctx->ffCount.ensure(sz.ffCount + slack));
+    HIP_TRY(ctx, ctx->groupSum.ensure(sz.groupSum + slack));
+    HIP_TRY(ctx, ctx->result.ensure(sz.result + slack));
+    HIP_TRY(ctx, ctx->unstuffed.ensure(sz.unstuffed + slack));
+    HIP_TRY(ctx, ctx->tileState.ensure(sz.tileState + slack));
     EntropyWorkspace& ws = ctx->ws;
     ws.ivOff = (unsigned long long*)ctx->ivOff.p;
     ws.ffCount = (uint32_t*)ctx->ffCount.p;
@@ -1096,6 +1099,25 @@ void batch_tables_worker(const jpeg_hip_ctx* ctx, int k0, int k1, const uint64_t
     }
 }
 
+// The entropy stage of images [a, a + cnt) of a batch pass, in its own slice of the workspace.
+struct BatchHalf {
+    int a = 0, cnt = 0;
+    KGeom k;
+    EntropyWorkspace ws;
+    BatchOutput bo;
+    uint64_t* off = nullptr;   // host: [cnt + 1] stream offsets, [cnt + 1] stuffing offsets, [4] result
+    const int16_t* coef = nullptr;
+    const uint32_t* tables = nullptr;
+};
+
+int launch_batch_half(jpeg_hip_ctx* ctx, BatchHalf& h) {
+    HIP_TRY(ctx, launch_entropy_batch(h.k, h.coef, h.tables, h.ws, h.bo, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h.off, h.ws.ivOff, (size_t)(h.cnt + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h.off + h.cnt + 1, h.bo.ffStart, (size_t)(h.cnt + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(h.off + 2 * (h.cnt + 1), h.ws.result, 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    return JPEG_HIP_OK;
+}
+
 // One pass: `n` images starting at d_rgb, output slots starting at d_out.
 int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStride, int n, uint8_t* d_out,
                       int64_t slotBytes, int64_t* lens) {
@@ -1120,8 +1142,67 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     k.firstInterval = 0;
     k.writeEoi = 1;
     const bool standard = ctx->prm.standard_huffman != 0;
-    int64_t totalBits = 0;
     int parts = 1;
+    // The entropy stage runs in two halves when the pass is cut into parts: the first half
+    // while the host still builds the tables of the second.
+    int nHalves = 1, tasksOfFirstHalf = 0;
+    int64_t halfBits[2] = {0, 0};
+    BatchHalf half[2];
+    bool marked3 = false;
+    auto start_half = [&](int hIdx, int64_t bitsOfHalf) -> int {
+        BatchHalf& h = half[hIdx];
+        h.ws.streamBound = bitsOfHalf < 0 ? (int64_t)h.cnt * slotBytes : bitsOfHalf / 8 + 3 * (int64_t)h.cnt + 2 + 64;
+        h.ws.avgBlockBits = bitsOfHalf < 0 ? -1 : bitsOfHalf / ((int64_t)h.cnt * g.totalBlocks);
+        h.ws.groupTile = group_tile_for(h.ws.avgBlockBits);
+        if (!marked3) mark(ctx, 3);
+        marked3 = true;
+        return launch_batch_half(ctx, h);
+    };
+    auto set_halves = [&](int firstCount) {
+        nHalves = firstCount > 0 && firstCount < n ? 2 : 1;
+        const WorkspaceSizes w0 = workspace_sizes(g, nHalves == 2 ? firstCount : n);
+        uint64_t* off = (uint64_t*)ctx->hostOffsets.p;
+        for (int i = 0; i < nHalves; ++i) {
+            BatchHalf& h = half[i];
+            h.a = i == 0 ? 0 : firstCount;
+            h.cnt = nHalves == 1 ? n : (i == 0 ? firstCount : n - firstCount);
+            h.k = k;
+            h.k.batch = h.cnt;
+            h.k.intervals = h.cnt;
+            h.k.nMcu = g.nMcu * h.cnt;
+            h.k.totalBlocks = g.totalBlocks * h.cnt;
+            h.k.groupMask = (const unsigned char*)ctx->gmask.p + (int64_t)h.a * g.totalBlocks;
+            h.coef = (const int16_t*)ctx->coef.p + (int64_t)h.a * g.totalBlocks * 64;
+            h.tables = (const uint32_t*)ctx->tables.p + (h.k.tableStride ? (size_t)h.a * 1024 : 0);
+            h.ws = ctx->ws;
+            h.ws.records = nullptr;
+            if (i == 1) {   // behind the first half's slices
+                h.ws.ivOff += firstCount + 1;
+                h.ws.ffCount += w0.maxChunks;
+                h.ws.groupSum += w0.maxChunks / 64 + 2;
+                h.ws.result += 4;
+                h.ws.unstuffed += w0.unstuffedCap;
+                h.ws.unstuffedCap = (int64_t)ctx->unstuffed.cap - w0.unstuffedCap;
+                h.ws.unstuffedCap = h.ws.unstuffedCap / 16 * 16;
+                h.ws.tileState += w0.tiles + 1;
+            } else if (nHalves == 2) {
+                h.ws.unstuffedCap = w0.unstuffedCap;
+            }
+            h.ws.maxChunks = (h.ws.unstuffedCap + kStuffChunk - 1) / kStuffChunk;
+            if (i == 1 || nHalves == 2) {
+                const WorkspaceSizes wi = workspace_sizes(g, h.cnt);
+                if (h.ws.unstuffedCap > wi.unstuffedCap) h.ws.unstuffedCap = wi.unstuffedCap;
+                h.ws.maxChunks = wi.maxChunks < h.ws.maxChunks ? wi.maxChunks : h.ws.maxChunks;
+            }
+            h.bo.out = d_out + (int64_t)h.a * slotBytes;
+            h.bo.slotBytes = slotBytes;
+            h.bo.hdr = (const uint8_t*)ctx->batchHdr.p + (size_t)h.a * kBatchHeaderPitch;
+            h.bo.hdrLen = (const uint32_t*)ctx->batchHdrLen.p + h.a;
+            h.bo.hdrPitch = kBatchHeaderPitch;
+            h.bo.ffStart = (unsigned long long*)ctx->batchFfStart.p + (i == 0 ? 0 : firstCount + 1);
+            h.off = off + (i == 0 ? 0 : 2 * (firstCount + 1) + 4);
+        }
+    };
     if (standard) {
         // One table set and one header serve every image; nothing waits for the host.
         mark(ctx, 0);
@@ -1144,7 +1225,8 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
             if (i > 0) memcpy(hdr + (size_t)i * kBatchHeaderPitch, hdr, (size_t)hn);
             hdrLen[i] = (uint32_t)hn;
         }
-        totalBits = -1;
+        halfBits[0] = -1;
+        set_halves(0);
     } else {
     // The histogram pass runs in up to eight parts, each followed (on a stream of its own, so
     // that the parts stay back to back) by the copy of its histograms: the host builds the
@@ -1159,6 +1241,7 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     const int groups = parts >= 4 ? 2 : 1;
     int partBegin[kBatchParts + 1];
     for (int p = 0; p <= parts; ++p) partBegin[p] = (int)((int64_t)n * p / parts);
+    set_halves(parts >= 2 ? partBegin[parts / 2] : 0);
     HIP_TRY(ctx, launch_clear_histograms((unsigned long long*)ctx->hist.p, n, ctx->stream));
     auto part_geometry = [&](int a, int cnt) {
         KGeom kp = k;
@@ -1229,13 +1312,26 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
                                     hipMemcpyHostToDevice, ctx->tableStream));
         HIP_TRY(ctx, hipMemcpyAsync((uint32_t*)ctx->batchHdrLen.p + a0, (const uint32_t*)ctx->hostHdrLen.p + a0, cnt * 4,
                                     hipMemcpyHostToDevice, ctx->tableStream));
+        if (p + 1 == parts / 2 && nHalves == 2) {
+            // The first half's tables are on their way: its entropy stage goes behind the last
+            // histogram pass and runs while the host builds the tables of the second half.
+            for (int t = 0; t < taskBase; ++t) {
+                if (status[(size_t)t] != JPEG_HIP_OK) return fail(ctx, status[(size_t)t], "Huffman tables or headers of a batch image could not be built");
+                halfBits[0] += bits[(size_t)t];
+            }
+            tasksOfFirstHalf = taskBase;
+            HIP_TRY(ctx, hipEventRecord(ctx->partCounted[0], ctx->tableStream));   // free again: its part was counted long ago
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->partCounted[0], 0));
+            const int st = start_half(0, halfBits[0]);
+            if (st != JPEG_HIP_OK) return st;
+        }
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->partCounted[0], ctx->tableStream));   // free again: its part was counted long ago
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->partCounted[0], 0));
+    HIP_TRY(ctx, hipEventRecord(ctx->partCounted[1 % parts], ctx->tableStream));   // free again: its part was counted long ago
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->partCounted[1 % parts], 0));
     for (int st : status)
         if (st != JPEG_HIP_OK) return fail(ctx, st, "Huffman tables or headers of a batch image could not be built");
     ctx->times[3] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    for (int64_t v : bits) totalBits += v;
+    for (size_t t = (size_t)tasksOfFirstHalf; t < bits.size(); ++t) halfBits[nHalves - 1] += bits[t];
     }
 
     if (standard) {
@@ -1244,32 +1340,28 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
                                     ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->batchHdrLen.p, ctx->hostHdrLen.p, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    BatchOutput bo;
-    bo.out = d_out;
-    bo.slotBytes = slotBytes;
-    bo.hdr = (const uint8_t*)ctx->batchHdr.p;
-    bo.hdrLen = (const uint32_t*)ctx->batchHdrLen.p;
-    bo.hdrPitch = kBatchHeaderPitch;
-    bo.ffStart = (unsigned long long*)ctx->batchFfStart.p;
-    // Without histograms the slots bound the stream: a longer one fails anyway.
-    ctx->ws.streamBound = totalBits < 0 ? (int64_t)n * slotBytes : totalBits / 8 + 3 * (int64_t)n + 2 + 64;
-    ctx->ws.avgBlockBits = totalBits < 0 ? -1 : totalBits / ((int64_t)n * g.totalBlocks);
-    ctx->ws.groupTile = group_tile_for(ctx->ws.avgBlockBits);
-    mark(ctx, 3);
-    uint64_t* off = (uint64_t*)ctx->hostOffsets.p;   // [n+1] stream offsets, [n+1] stuffing offsets, [4] result
-    for (int attempt = 0;; ++attempt) {
-        HIP_TRY(ctx, launch_entropy_batch(k, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, bo, ctx->stream));
-        if (attempt == 0) mark(ctx, 4);
-        HIP_TRY(ctx, hipMemcpyAsync(off, ctx->ivOff.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(off + n + 1, ctx->batchFfStart.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(off + 2 * (n + 1), ctx->result.p, 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, wait_stream(ctx));
+    // The last (or only) half.
+    {
+        const int st = start_half(nHalves - 1, halfBits[nHalves - 1]);
+        if (st != JPEG_HIP_OK) return st;
+    }
+    mark(ctx, 4);
+    HIP_TRY(ctx, wait_stream(ctx));
+    uint64_t flagsSeen = 0;
+    for (int i = 0; i < nHalves; ++i) {
+        BatchHalf& h = half[i];
         // Flags of the bit writer as in run_entropy_wait: a stage that was too small (8) or a
         // stream beyond the cleared bytes (4) are cured by a second run.
-        const uint64_t flags = off[2 * (n + 1) + 1];
-        if ((flags & (4 | 8)) == 0 || (flags & (2 | 16)) != 0 || attempt == 3) break;
-        if (flags & 4) ctx->ws.streamBound = -1;
-        if (flags & 8) ctx->ws.groupTile = ctx->ws.groupTile > 64 ? 64 : (ctx->ws.groupTile > 16 ? 16 : 0);
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            const uint64_t flags = h.off[2 * (h.cnt + 1) + 1];
+            if ((flags & (4 | 8)) == 0 || (flags & (2 | 16)) != 0) break;
+            if (flags & 4) h.ws.streamBound = -1;
+            if (flags & 8) h.ws.groupTile = h.ws.groupTile > 64 ? 64 : (h.ws.groupTile > 16 ? 16 : 0);
+            const int st = launch_batch_half(ctx, h);
+            if (st != JPEG_HIP_OK) return st;
+            HIP_TRY(ctx, wait_stream(ctx));
+        }
+        flagsSeen |= h.off[2 * (h.cnt + 1) + 1];
     }
     if (ctx->profiling) {
         float ms = 0;
@@ -1283,14 +1375,19 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
         }
         if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->times[2] += ms;
     }
-    if (off[2 * (n + 1) + 1] & 2) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer's tiles lost their chain");
-    if (off[2 * (n + 1) + 1] & 16) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "the Huffman tables have no code for a symbol of an image");
-    if (off[2 * (n + 1) + 1] & (4 | 8)) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer could not place its stream");
-    bool overflow = (off[2 * (n + 1) + 1] & 1) != 0;
+    if (flagsSeen & 2) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer's tiles lost their chain");
+    if (flagsSeen & 16) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "the Huffman tables have no code for a symbol of an image");
+    if (flagsSeen & (4 | 8)) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer could not place its stream");
+    bool overflow = (flagsSeen & 1) != 0;
     const uint32_t* hdrLen = (const uint32_t*)ctx->hostHdrLen.p;
-    for (int i = 0; i < n; ++i) {
-        lens[i] = (int64_t)hdrLen[i] + (int64_t)(off[i + 1] - off[i]) + (int64_t)(off[n + 1 + i + 1] - off[n + 1 + i]);
-        if (lens[i] > slotBytes) overflow = true;
+    for (int i = 0; i < nHalves; ++i) {
+        const BatchHalf& h = half[i];
+        for (int j = 0; j < h.cnt; ++j) {
+            const int img = h.a + j;
+            lens[img] = (int64_t)hdrLen[img] + (int64_t)(h.off[j + 1] - h.off[j]) +
+                        (int64_t)(h.off[h.cnt + 1 + j + 1] - h.off[h.cnt + 1 + j]);
+            if (lens[img] > slotBytes) overflow = true;
+        }
     }
     if (overflow) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "an output slot is too small for its image");
     return JPEG_HIP_OK;
@@ -1327,12 +1424,12 @@ int prepare_batch(jpeg_hip_ctx* ctx, const void* rgb, int sample_format, int64_t
     if (st != JPEG_HIP_OK) return st;
     HIP_TRY(ctx, ctx->batchHdr.ensure((size_t)pass * kBatchHeaderPitch));
     HIP_TRY(ctx, ctx->batchHdrLen.ensure((size_t)pass * 4));
-    HIP_TRY(ctx, ctx->batchFfStart.ensure((size_t)(pass + 1) * 8));
+    HIP_TRY(ctx, ctx->batchFfStart.ensure((size_t)(pass + 2) * 8));
     HIP_TRY(ctx, ctx->hostHist.ensure((size_t)pass * 1024 * 8));
     HIP_TRY(ctx, ctx->hostTables.ensure((size_t)pass * 1024 * 4));
     HIP_TRY(ctx, ctx->hostHdr.ensure((size_t)pass * kBatchHeaderPitch));
     HIP_TRY(ctx, ctx->hostHdrLen.ensure((size_t)pass * 4));
-    HIP_TRY(ctx, ctx->hostOffsets.ensure((size_t)(2 * (pass + 1) + 4) * 8));
+    HIP_TRY(ctx, ctx->hostOffsets.ensure((size_t)(2 * (pass + 2) + 8) * 8));
     ctx->times[0] = ctx->times[1] = ctx->times[2] = ctx->times[3] = 0;
     *passFrames = pass;
     return JPEG_HIP_OK;
