@@ -225,6 +225,7 @@ struct jpeg_hip_ctx {
     jpeghip::HostBuf uploadStage[2];                      // pinned blocks jpeg_hip_upload_pixels sends its pieces from
     hipEvent_t uploadEvent[2] = {nullptr, nullptr};
     jpeghip::DevBuf gather;                               // one channel's coefficients, contiguous (jpeg_hip_get_coefficients)
+    jpeghip::DevBuf tileSlots;                            // staged bits of the bit writer's tiles (EntropyWorkspace::tileSlots)
     jpeghip::DevBuf records, recCount;                    // symbol records of the current coefficients (launch_symbol_records)
     uint32_t recGeneration = 0;                  // number of the last launch that wrote them
     bool recordsValid = false;                   // they belong to the current coefficients

@@ -521,6 +521,10 @@ bool records_path_takes(const KGeom& g) {
 
 long long records_tiles(const KGeom& g) { return group_tiles_per_image(g.blocksPerImage, kGrpTileBlocks); }
 
+long long group_slot_bytes(const KGeom& g) {
+    return group_tiles_per_image(g.blocksPerImage, kGrpTileBlocks) * g.batch * (long long)kGrpSlotWords * 4;
+}
+
 hipError_t launch_symbol_records(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, bool clear,
                                  HistogramExport* ex, u32* d_records, u32* d_recCount, u32 generation) {
     if (clear) {
@@ -1101,9 +1105,21 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
                            ws.recCount, ws.recGeneration, d_tables, ws.tileState, runStart, ws.ivOff, ws.result,
                            (u32*)ws.unstuffed, zero);
     }
-    else if (groups)
-        hipLaunchKernelGGL(k_encode_groups, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, d_coef, d_tables, ws.tileState,
-                           ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero);
+    else if (groups && ws.tileSlots != nullptr && ws.groupTile == kGrpTileBlocks) {
+        // Nobody waits: the tiles leave their bits in slots, two small kernels find where every
+        // tile starts, a third puts the bits there (a tile that chains with a look-back spends a
+        // quarter of its life waiting for the slowest of the thousands of tiles in front of it).
+        hipLaunchKernelGGL(k_encode_groups<true>, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, d_coef, d_tables,
+                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero, ws.tileSlots);
+        const u32 runs = (u32)((tileCount + 63) / 64);
+        u64* runStart = ws.tileState + tileCount;   // (the buffer is sized for tiles of 16 blocks)
+        hipLaunchKernelGGL(k_group_positions, dim3(runs), dim3(64), 0, s, ws.tileState, runStart, (u32)tileCount);
+        hipLaunchKernelGGL(k_run_positions, dim3(1), dim3(1024), 0, s, g, runStart, runs);
+        hipLaunchKernelGGL(k_place_tiles, dim3((unsigned)((tileCount + 3) / 4)), dim3(256), 0, s, g, ws.tileState, runStart,
+                           ws.tileSlots, ws.ivOff, ws.result, (u32*)ws.unstuffed, (u32)tileCount, zero);
+    } else if (groups)
+        hipLaunchKernelGGL(k_encode_groups<false>, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, d_coef, d_tables, ws.tileState,
+                           ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero, nullptr);
     else if (shortBlocks)
         hipLaunchKernelGGL(k_encode_bits<true>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
                            ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult, zero);

@@ -266,8 +266,9 @@ __device__ __forceinline__ void stage_put(u32* st, u32 pos, u32 bits, u32 n) {
 }
 
 // Copies `bits` bits of the stage, starting at word srcWord, to the stream at bit position
-// dst, and clears them in the stage.  The stream is zero where nothing has been written yet;
-// the first and the last word of the range may be shared with neighbours and are merged.
+// dst, and (kClear) clears them in the stage.  The stream is zero where nothing has been
+// written yet; the first and the last word of the range may be shared with neighbours and are merged.
+template <bool kClear>
 __device__ __forceinline__ void stage_copy_out(u32* st, u32 srcWord, u32 bits, u64 dst, u32* __restrict__ words) {
     if (bits == 0) return;
     const int lane = threadIdx.x & 63;
@@ -284,13 +285,54 @@ __device__ __forceinline__ void stage_copy_out(u32* st, u32 srcWord, u32 bits, u
             words[w0 + i] = v;
         }
     }
-    for (u32 i = lane; i < nSrc; i += 64) st[srcWord + i] = 0;
+    if (kClear)
+        for (u32 i = lane; i < nSrc; i += 64) st[srcWord + i] = 0;
 }
 
+// What a tile leaves behind when its bits are placed by a later kernel (k_place_tiles): the
+// words of its stage, and the interval ends inside it.
+constexpr int kGrpSlotWords = kGrpStageWords + 4 + 2 * kGrpMaxFix;   // stage; number of ends, image, summary; blocks and offsets of the ends
+
+// Places a tile's staged bits at `start` and notes where its restart intervals end.  `st`: the
+// stage (LDS or the tile's slot), fixBlock / fixRel: nFix interval ends.
+template <bool kClear>
+__device__ __forceinline__ void place_tile(const KGeom& g, u32* st, PosSummary whole, u64 start, u32 nFix, const u32* fixBlock,
+                                           const u32* fixRel, u32 image, u64* __restrict__ ivOff, u64* __restrict__ result,
+                                           u32* __restrict__ words, long long zeroedBytes) {
+    const int lane = threadIdx.x & 63;
+    const u32 h = whole.x & 0x7fffffffu;
+    stage_copy_out<kClear>(st, 0, h, start, words);
+    if (whole.x >> 31) {
+        const u64 partStart = (start + h + 7) & ~7ull;
+        stage_copy_out<kClear>(st, (((h + 31u) & ~31u) + 32u) >> 5, whole.y, partStart, words);
+        if (g.padOnes && partStart != start + h && lane == 0) {   // the first end's padding, as one bits
+            const u64 at = start + h;
+            const u32 nPad = (u32)(partStart - at);
+            atomicOr(&words[at >> 5], __builtin_bswap32(((1u << nPad) - 1u) << (32u - (u32)(at & 31) - nPad)));
+        }
+        if ((u32)lane < nFix && (u32)lane < (u32)kGrpMaxFix) {
+            const u32 bl = fixBlock[lane];
+            const long long iv = g.batch > 1 ? (long long)image : (long long)((bl / (u32)g.bpm) / (u32)g.mcusPerInterval);
+            const u64 bytes = (partStart + fixRel[lane]) >> 3;
+            ivOff[iv + 1] = bytes;
+            if (iv + 1 == g.intervals) {
+                result[2] = bytes;
+                result[3] = (bytes + kStuffChunk - 1) / kStuffChunk;
+                if ((long long)bytes > zeroedBytes) atomicOr((unsigned long long*)&result[1], 4ull);
+            }
+        }
+    }
+}
+
+// kDeferred: the tile does not wait for its start position; it leaves its staged bits and its
+// summary behind (slots, state) and k_place_tiles puts them into the stream once every tile's
+// start is known.  Otherwise the tiles chain with a look-back and place their bits themselves.
+template <bool kDeferred>
 __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* __restrict__ coef,
                                                        const u32* __restrict__ tables, u64* __restrict__ state,
                                                        u64* __restrict__ ivOff, u64* __restrict__ result,
-                                                       u32* __restrict__ words, int tileBlocks, long long zeroedBytes) {
+                                                       u32* __restrict__ words, int tileBlocks, long long zeroedBytes,
+                                                       u32* __restrict__ slots) {
     __shared__ u32 tab[kTabWords];
     __shared__ unsigned short items[4][kGrpMaxItems + 2];
     __shared__ unsigned char roleTab[4][kGrpTileBlocks];
@@ -302,8 +344,9 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
     // Tiles per image in fours, so that the four tiles of a workgroup share their image's tables.
     const u32 tilesPerImage = (((u32)g.blocksPerImage + (u32)tileBlocks - 1) / (u32)tileBlocks + 3u) & ~3u;
     const long long tiles = (long long)tilesPerImage * g.batch;
-    // Tile numbers come from a counter: every predecessor of a running tile is running or done.
-    if (threadIdx.x == 0) ticket = atomicAdd((unsigned long long*)(state + tiles), 4ull);
+    // Tile numbers come from a counter: every predecessor of a running tile is running or done
+    // (nobody waits for anybody when the placement is deferred).
+    if (threadIdx.x == 0) ticket = kDeferred ? 4ull * blockIdx.x : atomicAdd((unsigned long long*)(state + tiles), 4ull);
     for (int i = threadIdx.x; i < 4 * kGrpStageWords; i += 256) (&stage[0][0])[i] = 0;
     __syncthreads();
     const u32 tile = (u32)__builtin_amdgcn_readfirstlane((u32)ticket) + (u32)wave;
@@ -518,9 +561,32 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
         }
     }
 
-    // The tile's summary is complete: publish it, find the tile's start, publish that.
     const PosSummary whole = {runX, runY};
     const u64 p0 = 8ull * (u64)interval_marker_bytes(g, 0);
+    u32 flags = 0;
+    if (__ballot(overflow) != 0) flags |= 8u;
+    if (__ballot(maxTok >= kTokAbsent) != 0) flags |= 16u;
+    if (kDeferred) {
+        // The tile's summary, its staged bits and its interval ends, for k_place_tiles.
+        u32* slot = slots + (size_t)tile * kGrpSlotWords;
+        const u32 h = whole.x & 0x7fffffffu;
+        const u32 used = (whole.x >> 31) ? ((((h + 31u) & ~31u) + 32u + whole.y + 31u) >> 5) : ((h + 31u) >> 5);
+        for (u32 i = lane; i < used && i < (u32)kGrpStageWords; i += 64) slot[i] = st[i];
+        if (lane == 0) {
+            state[tile] = ((u64)whole.x << 32) | whole.y;
+            slot[kGrpStageWords] = nFix;
+            slot[kGrpStageWords + 1] = image;
+            slot[kGrpStageWords + 2] = whole.x;
+            slot[kGrpStageWords + 3] = whole.y;
+        }
+        if ((u32)lane < nFix && (u32)lane < (u32)kGrpMaxFix) {
+            slot[kGrpStageWords + 4 + lane] = fixBlock[wave][lane];
+            slot[kGrpStageWords + 4 + kGrpMaxFix + lane] = fixRel[wave][lane];
+        }
+        if (flags != 0 && lane == 0) atomicOr((unsigned long long*)&result[1], (unsigned long long)flags);
+        return;
+    }
+    // The tile's summary is complete: publish it, find the tile's start, publish that.
     u64 start = p0;
     bool ok = true;
     if (tile > 0) {
@@ -532,35 +598,33 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
     if (!ok) start = p0;
     if (lane == 0)
         __hip_atomic_store(state + tile, kTilePosition | pos_apply(whole, start), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-    u32 flags = ok ? 0u : 2u;
-    if (__ballot(overflow) != 0) flags |= 8u;
-    if (__ballot(maxTok >= kTokAbsent) != 0) flags |= 16u;
-    const u32 h = whole.x & 0x7fffffffu;
-    stage_copy_out(st, 0, h, start, words);
-    if (whole.x >> 31) {
-        const u64 partStart = (start + h + 7) & ~7ull;
-        stage_copy_out(st, (((h + 31u) & ~31u) + 32u) >> 5, whole.y, partStart, words);
-        if (g.padOnes && partStart != start + h && lane == 0) {   // the first end's padding, as one bits
-            const u64 at = start + h;
-            const u32 nPad = (u32)(partStart - at);
-            atomicOr(&words[at >> 5], __builtin_bswap32(((1u << nPad) - 1u) << (32u - (u32)(at & 31) - nPad)));
-        }
-        if ((u32)lane < nFix && (u32)lane < (u32)kGrpMaxFix) {
-            const u32 bl = fixBlock[wave][lane];
-            const long long iv = g.batch > 1 ? (long long)image : (long long)((bl / (u32)g.bpm) / (u32)g.mcusPerInterval);
-            const u64 bytes = (partStart + fixRel[wave][lane]) >> 3;
-            ivOff[iv + 1] = bytes;
-            if (iv + 1 == g.intervals) {
-                result[2] = bytes;
-                result[3] = (bytes + kStuffChunk - 1) / kStuffChunk;
-                if ((long long)bytes > zeroedBytes) atomicOr((unsigned long long*)&result[1], 4ull);
-            }
-        }
-    }
+    if (!ok) flags |= 2u;
+    place_tile<true>(g, st, whole, start, nFix, fixBlock[wave], fixRel[wave], image, ivOff, result, words, zeroedBytes);
     if (tile == 0 && lane == 0) {
         ivOff[0] = 0;
         if (p0 != 0) atomicOr(&words[0], __builtin_bswap32((0xffd0u + (u32)((g.firstInterval - 1) & 7)) << 16));
     }
     if (flags != 0 && lane == 0) atomicOr((unsigned long long*)&result[1], (unsigned long long)flags);
+}
+
+// Deferred placement (see k_encode_groups): one wave per tile; state[tile] holds the summary of the
+// tiles in front of it inside its run of 64, runStart the position at which the run starts
+// (k_group_positions, k_run_positions).
+__global__ __launch_bounds__(256) void k_place_tiles(KGeom g, const u64* __restrict__ state, const u64* __restrict__ runStart,
+                                                     u32* __restrict__ slots, u64* __restrict__ ivOff, u64* __restrict__ result,
+                                                     u32* __restrict__ words, u32 tiles, long long zeroedBytes) {
+    const int lane = threadIdx.x & 63;
+    const u32 tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tile >= tiles) return;
+    const u64 before = state[tile];
+    const u64 start = pos_apply(PosSummary{(u32)(before >> 32), (u32)before}, runStart[tile >> 6]);
+    u32* slot = slots + (size_t)tile * kGrpSlotWords;
+    const u32 nFix = slot[kGrpStageWords], image = slot[kGrpStageWords + 1];
+    const PosSummary whole = {slot[kGrpStageWords + 2], slot[kGrpStageWords + 3]};
+    place_tile<false>(g, slot, whole, start, nFix, slot + kGrpStageWords + 4, slot + kGrpStageWords + 4 + kGrpMaxFix, image, ivOff,
+                      result, words, zeroedBytes);
+    if (tile == 0 && lane == 0) {
+        ivOff[0] = 0;
+        if (interval_marker_bytes(g, 0) != 0) atomicOr(&words[0], __builtin_bswap32((0xffd0u + (u32)((g.firstInterval - 1) & 7)) << 16));
+    }
 }

@@ -73,6 +73,9 @@ struct EntropyWorkspace {
     long long streamBound;           // upper bound of the unstuffed stream in bytes, or < 0 when unknown
     long long avgBlockBits;          // mean entropy-coded bits per block according to the histograms, or < 0 when unknown
     int groupTile;                   // blocks per tile of the bit writer on groups: 256, 64 or 16; 0: the one-lane-per-block writer
+    // Room for the staged bits of the tiles of 256 blocks (group_slot_bytes), or null: the tiles
+    // then chain with a look-back and place their bits themselves.
+    uint32_t* tileSlots;
     // Symbol records of the current coefficients (launch_symbol_records), or null: the bit
     // writer then reads the coefficients themselves.
     const uint32_t* records;
@@ -134,6 +137,7 @@ hipError_t launch_clear_histograms(unsigned long long* d_hist, int images, hipSt
 // words; d_recCount: 1 + records_tiles(g) words, the first one zero before the first launch.
 constexpr int kRecordsPerTile = 6144;
 bool records_path_takes(const KGeom& g);
+long long group_slot_bytes(const KGeom& g);   // EntropyWorkspace::tileSlots
 long long records_tiles(const KGeom& g);
 hipError_t launch_symbol_records(const KGeom& g, const int16_t* d_coef, unsigned long long* d_hist, hipStream_t s, bool clear,
                                  HistogramExport* ex, uint32_t* d_records, uint32_t* d_recCount, uint32_t generation);

@@ -18,10 +18,12 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def ctx():
     os.environ["JPEGENC_GROUP_MIN_BLOCKS"] = "0"
+    os.environ["JPEGENC_SLOTS_MIN_BLOCKS"] = "0"      # tiles of 256 blocks leave their bits in slots (deferred placement)
     c = B.Context(0)
     yield c
     c.close()
     os.environ.pop("JPEGENC_GROUP_MIN_BLOCKS", None)
+    os.environ.pop("JPEGENC_SLOTS_MIN_BLOCKS", None)
     os.environ.pop("JPEGENC_GROUP_TILE", None)
 
 
@@ -140,3 +142,19 @@ def test_two_pass_form_with_symbol_records(ctx, scheme):
             assert ctx.encode_host(img, prm) == enc.jpeg, (scheme, w, h, kind, tname, ri, pad)
     finally:
         os.environ.pop("JPEGENC_RECORDS", None)
+
+
+def test_tiles_that_chain_with_a_look_back(ctx):
+    """The other way to place a tile's bits (the tile waits for its start and writes them itself),
+    which small images and the smaller tiles take."""
+    _tile(256)
+    os.environ["JPEGENC_SLOTS_MIN_BLOCKS"] = "1000000000"
+    try:
+        for (w, h, kind, ri, pad) in [(640, 360, "natural", 0, False), (331, 203, "noise", 8, True), (331, 203, "natural", 40, False)]:
+            img = synth.generate(kind, w, h, seed=w + h)
+            qt = T.quality_tables(90)
+            enc = O.encode(img, T.SCHEMES["420"], qt, restart_interval=ri, pad_ones=pad)
+            prm = B.make_params(w, h, T.SCHEMES["420"], qt, restart_interval=ri, pad_ones=pad)
+            assert ctx.encode_host(img, prm) == enc.jpeg, (w, h, kind, ri, pad)
+    finally:
+        os.environ["JPEGENC_SLOTS_MIN_BLOCKS"] = "0"
