@@ -1167,6 +1167,9 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
         marked3 = true;
         return launch_batch_half(ctx, h);
     };
+    // Room for the staged bits of every tile (deferred placement, see run_entropy_launch).
+    uint32_t* slots = nullptr;
+    if (!ctx->staticWorkspace && ctx->tileSlots.ensure((size_t)group_slot_bytes(k)) == hipSuccess) slots = (uint32_t*)ctx->tileSlots.p;
     auto set_halves = [&](int firstCount) {
         nHalves = firstCount > 0 && firstCount < n ? 2 : 1;
         const WorkspaceSizes w0 = workspace_sizes(g, nHalves == 2 ? firstCount : n);
@@ -1185,6 +1188,7 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
             h.tables = (const uint32_t*)ctx->tables.p + (h.k.tableStride ? (size_t)h.a * 1024 : 0);
             h.ws = ctx->ws;
             h.ws.records = nullptr;
+            h.ws.tileSlots = slots ? slots + (i == 1 ? group_slot_bytes(half[0].k) / 4 : 0) : nullptr;
             if (i == 1) {   // behind the first half's slices
                 h.ws.ivOff += firstCount + 1;
                 h.ws.ffCount += w0.maxChunks;
