@@ -200,7 +200,9 @@ def main():
         return B.Communicator(uid.cpu().numpy(), rank, world, local_rank)
 
     comms = [make_comm()] if use_rccl else [None]
-    collective = None
+    # What the exchange step ran on; with one rank there is none (the image is one band).
+    collective = {"backend": "none (one rank, no exchange step)", "world_size": 1,
+                  "devices": [torch.cuda.get_device_name(local_rank)]}
     if world > 1:
         names = [None] * world
         dist.all_gather_object(names, "cuda:%d %s" % (local_rank, torch.cuda.get_device_name(local_rank)))
