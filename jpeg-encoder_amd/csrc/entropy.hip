@@ -1117,6 +1117,8 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
         hipLaunchKernelGGL(k_run_positions, dim3(1), dim3(1024), 0, s, g, runStart, runs);
         hipLaunchKernelGGL(k_place_tiles, dim3((unsigned)((tileCount + 3) / 4)), dim3(256), 0, s, g, ws.tileState, runStart,
                            ws.tileSlots, ws.ivOff, ws.result, (u32*)ws.unstuffed, (u32)tileCount, zero);
+        hipLaunchKernelGGL(k_merge_edges, dim3((unsigned)((4 * tileCount + 255) / 256)), dim3(256), 0, s, g, ws.tileSlots,
+                           (u32*)ws.unstuffed, (u32)tileCount);
     } else if (groups)
         hipLaunchKernelGGL(k_encode_groups<false>, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, d_coef, d_tables, ws.tileState,
                            ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero, nullptr);

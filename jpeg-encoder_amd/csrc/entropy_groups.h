@@ -289,23 +289,91 @@ __device__ __forceinline__ void stage_copy_out(u32* st, u32 srcWord, u32 bits, u
         for (u32 i = lane; i < nSrc; i += 64) st[srcWord + i] = 0;
 }
 
+// The same from a tile's slot in global memory.  All reads are issued before the first word is
+// written: a loop that reads, merges and writes word by word waits for its own stores and
+// atomics (one counter tracks them all), i.e. for several round trips to memory instead of one.
+constexpr int kSlotCopyRounds = (kGrpStageWords + 1 + 63) / 64;
+constexpr int kGrpSlotHead = kGrpStageWords + 64;   // where a slot's header starts
+constexpr int kGrpSlotEdges = kGrpSlotHead + 4 + 2 * 24;   // where the four edge entries of a slot lie (8-byte aligned)
+constexpr int kGrpSlotWords = kGrpSlotEdges + 8;   // stage and a row of slack; number of ends, image, summary; blocks and offsets of the ends; edges
+
+__device__ __forceinline__ void slot_load(const u32* __restrict__ slot, u32 srcWord, u32 (&lo)[kSlotCopyRounds]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < kSlotCopyRounds; ++k) {   // reads behind the part stay inside the slot and are dropped later
+        const u32 i = srcWord + (u32)lane + 64u * k;
+        lo[k] = slot[i < (u32)kGrpSlotWords ? i : (u32)kGrpSlotWords - 1u];
+    }
+}
+
+// edge: where the first and the last word of the range go when they may be shared with a
+// neighbour (two 64-bit entries, word number << 32 | bits, kNoEdge for none); k_merge_edges puts
+// them into the stream.  An atomic at device scope instead costs the placing kernel half its time.
+constexpr u64 kNoEdge = ~0ull;
+
+// padN one bits at bit position padAt (the padding behind an interval end, when it is made of ones)
+// are merged into the word they fall into, which is the range's last.
+__device__ __forceinline__ void slot_place(u32 (&lo)[kSlotCopyRounds], u32 bits, u64 dst, u32* __restrict__ words,
+                                           u64* __restrict__ edge, u64 padAt = 0, u32 padN = 0) {
+    const int lane = threadIdx.x & 63;
+    if (bits == 0) {
+        if (lane == 0) edge[0] = edge[1] = kNoEdge;
+        return;
+    }
+    const u32 s = (u32)(dst & 31);
+    const u64 w0 = dst >> 5;
+    const u32 nSrc = (bits + 31) >> 5, nOut = (s + bits + 31) >> 5;
+#pragma unroll
+    for (int k = 0; k < kSlotCopyRounds; ++k)
+        if ((u32)lane + 64u * k >= nSrc) lo[k] = 0;
+    if (lane == 0 && nOut == 1) edge[1] = kNoEdge;
+#pragma unroll
+    for (int k = 0; k < kSlotCopyRounds; ++k) {
+        const u32 i = (u32)lane + 64u * k;
+        // the word in front of this one: the neighbour lane's, or lane 63's of the round before
+        const u32 before = k > 0 ? (u32)__builtin_amdgcn_readlane(lo[k > 0 ? k - 1 : 0], 63) : 0u;
+        const u32 hi = __builtin_amdgcn_update_dpp(before, lo[k], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (i < nOut) {
+            u32 v = __builtin_bswap32(__builtin_amdgcn_alignbit(hi, lo[k], s));
+            if (padN != 0 && w0 + i == (padAt >> 5)) v |= __builtin_bswap32(((1u << padN) - 1u) << (32u - (u32)(padAt & 31) - padN));
+            if (i == 0) edge[0] = ((w0 + i) << 32) | v;
+            else if (i == nOut - 1) edge[1] = ((w0 + i) << 32) | v;
+            else words[w0 + i] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ void slot_copy_out(const u32* __restrict__ slot, u32 srcWord, u32 bits, u64 dst,
+                                              u32* __restrict__ words, u64* __restrict__ edge) {
+    u32 lo[kSlotCopyRounds];
+    slot_load(slot, srcWord, lo);
+    slot_place(lo, bits, dst, words, edge);
+}
+
 // What a tile leaves behind when its bits are placed by a later kernel (k_place_tiles): the
 // words of its stage, and the interval ends inside it.
-constexpr int kGrpSlotWords = kGrpStageWords + 4 + 2 * kGrpMaxFix;   // stage; number of ends, image, summary; blocks and offsets of the ends
+static_assert(kGrpMaxFix == 24, "the slot's size is written out above");
 
 // Places a tile's staged bits at `start` and notes where its restart intervals end.  `st`: the
 // stage (LDS or the tile's slot), fixBlock / fixRel: nFix interval ends.
 template <bool kClear>
 __device__ __forceinline__ void place_tile(const KGeom& g, u32* st, PosSummary whole, u64 start, u32 nFix, const u32* fixBlock,
                                            const u32* fixRel, u32 image, u64* __restrict__ ivOff, u64* __restrict__ result,
-                                           u32* __restrict__ words, long long zeroedBytes) {
+                                           u32* __restrict__ words, long long zeroedBytes, u32 partWord = ~0u) {
+    // partWord: word of the stage at which the part behind the first interval end starts (given
+    // by a caller that has placed the part in front of it already and passes h = 0 with its end as `start`).
     const int lane = threadIdx.x & 63;
     const u32 h = whole.x & 0x7fffffffu;
-    stage_copy_out<kClear>(st, 0, h, start, words);
+    const bool frontDone = partWord != ~0u;
+    if (!frontDone) partWord = (((h + 31u) & ~31u) + 32u) >> 5;
+    u64* edges = (u64*)(st + kGrpSlotEdges);   // (slots only)
+    if (kClear) stage_copy_out<true>(st, 0, h, start, words);   // (kClear: the stage in LDS; otherwise a slot in memory)
+    else if (!frontDone) slot_copy_out(st, 0, h, start, words, edges);
     if (whole.x >> 31) {
         const u64 partStart = (start + h + 7) & ~7ull;
-        stage_copy_out<kClear>(st, (((h + 31u) & ~31u) + 32u) >> 5, whole.y, partStart, words);
-        if (g.padOnes && partStart != start + h && lane == 0) {   // the first end's padding, as one bits
+        if (kClear) stage_copy_out<true>(st, partWord, whole.y, partStart, words);
+        else slot_copy_out(st, partWord, whole.y, partStart, words, edges + 2);
+        if (kClear && g.padOnes && partStart != start + h && lane == 0) {   // the first end's padding, as one bits (slots: see slot_place)
             const u64 at = start + h;
             const u32 nPad = (u32)(partStart - at);
             atomicOr(&words[at >> 5], __builtin_bswap32(((1u << nPad) - 1u) << (32u - (u32)(at & 31) - nPad)));
@@ -574,14 +642,14 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
         for (u32 i = lane; i < used && i < (u32)kGrpStageWords; i += 64) slot[i] = st[i];
         if (lane == 0) {
             state[tile] = ((u64)whole.x << 32) | whole.y;
-            slot[kGrpStageWords] = nFix;
-            slot[kGrpStageWords + 1] = image;
-            slot[kGrpStageWords + 2] = whole.x;
-            slot[kGrpStageWords + 3] = whole.y;
+            slot[kGrpSlotHead] = nFix;
+            slot[kGrpSlotHead + 1] = image;
+            slot[kGrpSlotHead + 2] = whole.x;
+            slot[kGrpSlotHead + 3] = whole.y;
         }
         if ((u32)lane < nFix && (u32)lane < (u32)kGrpMaxFix) {
-            slot[kGrpStageWords + 4 + lane] = fixBlock[wave][lane];
-            slot[kGrpStageWords + 4 + kGrpMaxFix + lane] = fixRel[wave][lane];
+            slot[kGrpSlotHead + 4 + lane] = fixBlock[wave][lane];
+            slot[kGrpSlotHead + 4 + kGrpMaxFix + lane] = fixRel[wave][lane];
         }
         if (flags != 0 && lane == 0) atomicOr((unsigned long long*)&result[1], (unsigned long long)flags);
         return;
@@ -616,15 +684,67 @@ __global__ __launch_bounds__(256) void k_place_tiles(KGeom g, const u64* __restr
     const int lane = threadIdx.x & 63;
     const u32 tile = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (tile >= tiles) return;
-    const u64 before = state[tile];
-    const u64 start = pos_apply(PosSummary{(u32)(before >> 32), (u32)before}, runStart[tile >> 6]);
     u32* slot = slots + (size_t)tile * kGrpSlotWords;
-    const u32 nFix = slot[kGrpStageWords], image = slot[kGrpStageWords + 1];
-    const PosSummary whole = {slot[kGrpStageWords + 2], slot[kGrpStageWords + 3]};
-    place_tile<false>(g, slot, whole, start, nFix, slot + kGrpStageWords + 4, slot + kGrpStageWords + 4 + kGrpMaxFix, image, ivOff,
-                      result, words, zeroedBytes);
-    if (tile == 0 && lane == 0) {
-        ivOff[0] = 0;
-        if (interval_marker_bytes(g, 0) != 0) atomicOr(&words[0], __builtin_bswap32((0xffd0u + (u32)((g.firstInterval - 1) & 7)) << 16));
+    // Everything that does not depend on anything else is asked for at once: the tile's place
+    // in its run, the run's start, the slot's header, and the words of the part in front of the
+    // first interval end (as many as a stage holds; the length decides later which count).
+    u32 lo[kSlotCopyRounds];
+    slot_load(slot, 0, lo);
+    const u64 before = state[tile];
+    const u64 runAt = runStart[tile >> 6];
+    const u32 nFix = slot[kGrpSlotHead], image = slot[kGrpSlotHead + 1];
+    const PosSummary whole = {slot[kGrpSlotHead + 2], slot[kGrpSlotHead + 3]};
+    const u64 start = pos_apply(PosSummary{(u32)(before >> 32), (u32)before}, runAt);
+    const u32 h = whole.x & 0x7fffffffu;
+    u64* edges = (u64*)(slot + kGrpSlotEdges);
+    const u64 at = start + h;
+    const u32 padN = (whole.x >> 31) && g.padOnes ? (u32)(((at + 7) & ~7ull) - at) : 0u;
+    slot_place(lo, h, start, words, edges, at, padN);
+    if ((whole.x >> 31) == 0) {
+        if (lane == 0) edges[2] = edges[3] = kNoEdge;
+    } else {
+        place_tile<false>(g, slot, PosSummary{0x80000000u, whole.y}, at, nFix, slot + kGrpSlotHead + 4,
+                          slot + kGrpSlotHead + 4 + kGrpMaxFix, image, ivOff, result, words, zeroedBytes, (((h + 31u) & ~31u) + 32u) >> 5);
     }
+    if (tile == 0 && lane == 0) ivOff[0] = 0;
+}
+
+// The stream words at the edges of the tiles' parts: entries with the same word number are
+// ORed together (neighbours meet inside a word) and the first of such a run writes the word.
+// A band that does not begin the image starts with the RSTn of the interval in front of it.
+__global__ __launch_bounds__(256) void k_merge_edges(KGeom g, const u32* __restrict__ slots, u32* __restrict__ words, u32 tiles) {
+    const long long n = 4ll * tiles;
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    auto entry = [&](long long k) { return ((const u64*)(slots + (size_t)(k >> 2) * kGrpSlotWords + kGrpSlotEdges))[k & 3]; };
+    if (c == 0 && interval_marker_bytes(g, 0) != 0) {
+        // bits 31..16 of word 0; the first tile's first entry, if it lies in word 0 too, brings the rest
+        u32 v = __builtin_bswap32((0xffd0u + (u32)((g.firstInterval - 1) & 7)) << 16);
+        for (long long k = 0; k < n; ++k) {
+            const u64 e = entry(k);
+            if (e == kNoEdge) continue;
+            if ((e >> 32) != 0) break;
+            v |= (u32)e;
+        }
+        words[0] = v;
+        return;
+    }
+    if (c >= n) return;
+    const u64 mine = entry(c);
+    if (mine == kNoEdge) return;
+    const u64 w = mine >> 32;
+    if (w == 0 && interval_marker_bytes(g, 0) != 0) return;   // written above
+    for (long long k = c - 1; k >= 0; --k) {   // is there an entry for the same word in front?  then that one writes
+        const u64 e = entry(k);
+        if (e == kNoEdge) continue;
+        if ((e >> 32) == w) return;
+        break;
+    }
+    u32 v = (u32)mine;
+    for (long long k = c + 1; k < n; ++k) {
+        const u64 e = entry(k);
+        if (e == kNoEdge) continue;
+        if ((e >> 32) != w) break;
+        v |= (u32)e;
+    }
+    words[w] = v;
 }
