@@ -307,10 +307,8 @@ __device__ __forceinline__ f2 unorm8_pair(u32 wa, u32 wb, int k) {
     return fma2(x, splat(INV255_HI), x * INV255_LO);
 }
 
-__device__ __forceinline__ void pixel_ycbcr_pair(const u32 (&ra)[6], const u32 (&rb)[6], int i, f2& y, f2& cb, f2& cr) {
-    const f2 r = unorm8_pair(ra[(3 * i) >> 2], rb[(3 * i) >> 2], (3 * i) & 3);
-    const f2 g = unorm8_pair(ra[(3 * i + 1) >> 2], rb[(3 * i + 1) >> 2], (3 * i + 1) & 3);
-    const f2 b = unorm8_pair(ra[(3 * i + 2) >> 2], rb[(3 * i + 2) >> 2], (3 * i + 2) & 3);
+// The colour matrix (SIMD256.h:155-186) on the same pixel of two rows.
+__device__ __forceinline__ void ycbcr_pair(f2 r, f2 g, f2 b, f2& y, f2& cb, f2& cr) {
     f2 t = r * 0.2990f;
     t = t + g * 0.5870f;
     y = t + b * 0.1140f;
@@ -322,6 +320,13 @@ __device__ __forceinline__ void pixel_ycbcr_pair(const u32 (&ra)[6], const u32 (
     t = t + g * -0.4186f;
     t = t + b * -0.0813f;
     cr = t + 0.5f;
+}
+
+__device__ __forceinline__ void pixel_ycbcr_pair(const u32 (&ra)[6], const u32 (&rb)[6], int i, f2& y, f2& cb, f2& cr) {
+    const f2 r = unorm8_pair(ra[(3 * i) >> 2], rb[(3 * i) >> 2], (3 * i) & 3);
+    const f2 g = unorm8_pair(ra[(3 * i + 1) >> 2], rb[(3 * i + 1) >> 2], (3 * i + 1) & 3);
+    const f2 b = unorm8_pair(ra[(3 * i + 2) >> 2], rb[(3 * i + 2) >> 2], (3 * i + 2) & 3);
+    ycbcr_pair(r, g, b, y, cb, cr);
 }
 
 // x255 (SIMD256.h:484-494), transform, quantize, zig-zag: row-pair values in, the block's
@@ -440,13 +445,14 @@ __device__ __forceinline__ void finish_block_staged(f2 (&a)[32], const float* __
 // Luma variant for the 4:2:0 kernel: lane l holds block (l & 3) of the wave's MCU (l >> 2);
 // an MCU's four luma blocks are contiguous (512 bytes), MCUs are six blocks apart.  Two
 // half-wave rounds through a 32-block stage.
+template <bool kClamp = false>
 __device__ __forceinline__ void finish_block_staged_y(f2 (&a)[32], const float* __restrict__ rhi,
                                                       const float* __restrict__ rlo, unsigned char* stage,
                                                       int16_t* __restrict__ waveBase, unsigned char* __restrict__ waveMask,
                                                       int mcuCount) {
     const int lane = threadIdx.x & 63;
     u32 p[32];
-    transform_quantize_pairs(a, rhi, rlo, p);
+    transform_quantize_pairs<kClamp>(a, rhi, rlo, p);
     if ((lane >> 2) < mcuCount) waveMask[(lane >> 2) * 6 + (lane & 3)] = (unsigned char)group_mask(p);
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
@@ -563,6 +569,119 @@ __global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned c
         }
         finish_block_staged<2>(a, rhi + 64 * (1 + ch), rlo + 64 * (1 + ch), stage + wave * 32 * kStagePitch,
                                coef + (mBase * 6 + 4 + ch) * 64, gmask + mBase * 6 + 4 + ch, 6, mcuCount);
+    }
+}
+
+// 4:2:0 from float pixels (Image::setRawPixelData's input, values in 0..1): k_transform_420 with
+// 96-byte rows.  A thread's eight rows are 768 bytes, too many registers to ask for at once and
+// too many round trips to ask for one by one: two rows are converted while the next two are on
+// their way.  Rows start on 16-byte boundaries (the launcher checks); blocks that reach past
+// the image read single floats with the edge replicated.
+__device__ __forceinline__ void load_rows2f(const unsigned char* __restrict__ rgb, long long stride, int x0, int y, bool interior,
+                                            int W, int rows, float (&ra)[24], float (&rb)[24]) {
+    if (interior) {
+        const float4* pa = (const float4*)(rgb + (long long)y * stride + (long long)x0 * 12);
+        const float4* pb = (const float4*)(rgb + (long long)(y + 1) * stride + (long long)x0 * 12);
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+            const float4 u = pa[d], v = pb[d];
+            ra[4 * d] = u.x; ra[4 * d + 1] = u.y; ra[4 * d + 2] = u.z; ra[4 * d + 3] = u.w;
+            rb[4 * d] = v.x; rb[4 * d + 1] = v.y; rb[4 * d + 2] = v.z; rb[4 * d + 3] = v.w;
+        }
+    } else {
+        const unsigned char* rowA = rgb + (long long)min(y, rows - 1) * stride;
+        const unsigned char* rowB = rgb + (long long)min(y + 1, rows - 1) * stride;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long long off = (long long)min(x0 + i, W - 1) * 12;
+            const float* a = (const float*)(rowA + off);
+            const float* b = (const float*)(rowB + off);
+            ra[3 * i] = a[0]; ra[3 * i + 1] = a[1]; ra[3 * i + 2] = a[2];
+            rb[3 * i] = b[0]; rb[3 * i + 1] = b[1]; rb[3 * i + 2] = b[2];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_transform_420f(KGeom g, const unsigned char* __restrict__ rgb,
+                                                        const float* __restrict__ qtab, int16_t* __restrict__ coef,
+                                                        unsigned char* __restrict__ gmask, u64* __restrict__ clearHist) {
+    clear_histograms(clearHist);
+    __shared__ __attribute__((aligned(16))) float chroma[2 * k420Mcus * kChromaPitch];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4 * 32 * kStagePitch];
+    const float* rhi = qtab + 192;
+    const float* rlo = qtab + 384;
+    const int tid = threadIdx.x, q = tid & 3, ml = tid >> 2;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long mBase = (long long)blockIdx.x * k420Mcus;
+    const long long left = g.nMcu - mBase;
+    const int mcuCount = left < k420Mcus ? (int)left : k420Mcus;
+    const long long m = mBase + (ml < mcuCount ? ml : mcuCount - 1);   // idle lanes redo the last MCU, store nothing
+    {
+        int mx, my;
+        rgb += locate_mcu(g, m, mx, my);
+        const int x0 = mx * 16 + (q & 1) * 8, y0 = my * 16 + (q >> 1) * 8;
+        const bool interior = x0 + 8 <= g.W && y0 + 8 <= g.rowsAvail;
+        f2 a[32];   // a[rp * 8 + i] = Y of pixel i in rows 2rp and 2rp + 1
+        float* cbDst = chroma + ml * kChromaPitch + (q >> 1) * 32 + (q & 1) * 8;   // layout as in k_transform_420
+        float* crDst = cbDst + k420Mcus * kChromaPitch;
+        float ra[24], rb[24];
+        load_rows2f(rgb, g.strideBytes, x0, y0, interior, g.W, g.rowsAvail, ra, rb);
+        float ecb[4], ecr[4];   // chroma row of the even row pair, waiting for its odd partner
+#pragma unroll
+        for (int rp = 0; rp < 4; ++rp) {
+            f2 cb[8], cr[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                ycbcr_pair((f2){ra[3 * i], rb[3 * i]}, (f2){ra[3 * i + 1], rb[3 * i + 1]}, (f2){ra[3 * i + 2], rb[3 * i + 2]},
+                           a[8 * rp + i], cb[i], cr[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            // The rows are used up: the next two are asked for into the same registers and travel
+            // while the chroma of these two is folded.
+            if (rp < 3) load_rows2f(rgb, g.strideBytes, x0, y0 + 2 * rp + 2, interior, g.W, g.rowsAvail, ra, rb);
+            __builtin_amdgcn_sched_barrier(0);
+            float ocb[4], ocr[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // (a + b) / 2.0f across, both rows at once (SIMD256.h:260-277), then
+                // (row0 + row1) / 2.0f down (SIMD256.h:295-304).
+                const f2 hcb = (cb[2 * j] + cb[2 * j + 1]) * 0.5f;
+                const f2 hcr = (cr[2 * j] + cr[2 * j + 1]) * 0.5f;
+                ocb[j] = (hcb.x + hcb.y) * 0.5f;
+                ocr[j] = (hcr.x + hcr.y) * 0.5f;
+            }
+            if ((rp & 1) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ecb[j] = ocb[j];
+                    ecr[j] = ocr[j];
+                }
+            } else {   // chroma rows (q >> 1) * 4 + rp - 1 and + rp form a pair
+                float* db = cbDst + (rp >> 1) * 16;
+                float* dr = crDst + (rp >> 1) * 16;
+                *(float4*)db = make_float4(ecb[0], ocb[0], ecb[1], ocb[1]);
+                *(float4*)(db + 4) = make_float4(ecb[2], ocb[2], ecb[3], ocb[3]);
+                *(float4*)dr = make_float4(ecr[0], ocr[0], ecr[1], ocr[1]);
+                *(float4*)(dr + 4) = make_float4(ecr[2], ocr[2], ecr[3], ocr[3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int waveMcus = mcuCount - wave * 16;   // MCUs of this wave that exist (may be <= 0)
+        finish_block_staged_y<true>(a, rhi, rlo, stage + wave * 32 * kStagePitch, coef + (mBase + wave * 16) * 6 * 64,
+                                    gmask + (mBase + wave * 16) * 6, waveMcus);
+    }
+    __syncthreads();
+    if (tid < 2 * k420Mcus) {
+        const int ch = wave;   // wave 0: Cb, wave 1: Cr
+        const float4* src = (const float4*)(chroma + (ch * k420Mcus + (tid & 63)) * kChromaPitch);
+        f2 a[32];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 t = src[i];
+            a[2 * i] = (f2){t.x, t.y};
+            a[2 * i + 1] = (f2){t.z, t.w};
+        }
+        finish_block_staged<2, true>(a, rhi + 64 * (1 + ch), rlo + 64 * (1 + ch), stage + wave * 32 * kStagePitch,
+                                     coef + (mBase * 6 + 4 + ch) * 64, gmask + mBase * 6 + 4 + ch, 6, mcuCount);
     }
 }
 
@@ -1019,6 +1138,11 @@ hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qt
         const long long grid = (g.nMcu + 63) / 64;
         hipLaunchKernelGGL(k_transform_rows<false>, dim3((unsigned)grid), dim3(64 * g.bpm), 0, s, g,
                            (const unsigned char*)d_rgb, d_qtab, d_coef, d_gmask, d_clearHist);
+    } else if (g.sampleFormat == JPEG_HIP_RGBF32 && g.nGains == 0 && g.stages == JPEG_HIP_STAGE_ALL && scheme_is(g, 2, 2, JPEG_HIP_AVERAGE) &&
+               (((uintptr_t)d_rgb | (uintptr_t)g.strideBytes | (uintptr_t)g.imageStrideBytes) & 15) == 0) {
+        const long long grid = (g.nMcu + k420Mcus - 1) / k420Mcus;
+        hipLaunchKernelGGL(k_transform_420f, dim3((unsigned)grid), dim3(256), 0, s, g, (const unsigned char*)d_rgb, d_qtab, d_coef,
+                           d_gmask, d_clearHist);
     } else if (g.sampleFormat == JPEG_HIP_RGBF32 && g.nGains == 0 && rows_kernel_takes(g)) {   // any stages, any scheme
         const long long grid = (g.nMcu + 63) / 64;
         hipLaunchKernelGGL(k_transform_rows<true>, dim3((unsigned)grid), dim3(64 * g.bpm), 0, s, g,

@@ -68,6 +68,19 @@ def test_float_pixels(ctx):
         assert ctx.encode_host(img, prm) == enc.jpeg
 
 
+@pytest.mark.parametrize("w,h", [(4, 4), (16, 16), (64, 48), (332, 270), (1028, 36), (70, 45)])
+def test_float_pixels_420_row_pair_form(ctx, w, h):
+    # Rows of w*12 bytes are 16-byte aligned when w is a multiple of 4: those sizes take the
+    # kernel that asks for whole row pairs ahead; 70 takes the general one.  Values outside
+    # [0,1] reach the clamp of the level shift, ragged sizes the edge replication.
+    rng = np.random.RandomState(w * 7 + h)
+    img = (rng.rand(h, w, 3) * 1.4 - 0.2).astype(np.float32)
+    for ri in (0, 5):
+        enc = O.encode(img, T.SCHEMES["420"], T.STANDARD_TABLES, restart_interval=ri)
+        prm = B.make_params(w, h, T.SCHEMES["420"], T.STANDARD_TABLES, restart_interval=ri)
+        assert ctx.encode_host(img, prm) == enc.jpeg, (w, h, ri)
+
+
 def test_float_planes_like_the_reference_image(ctx):
     # Three planes with the reference's layout: padded to whole MCUs ("simulated" size), the
     # border filled with anything -- only the image's own samples may be read.
