@@ -278,6 +278,35 @@ __device__ __forceinline__ u64 block_exclusive_scan(u64 v, u64* lds, u64& total)
     return base + inc - v;
 }
 
+// The same for a caller with loads in flight that the barriers must not wait for: the barriers
+// order the accesses to `lds` only (u32 values, a workgroup of 256).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the LDS accesses, not the loads from memory
+    __builtin_amdgcn_s_barrier();
+}
+
+__device__ __forceinline__ u32 block_exclusive_scan_lds(u32 v, u32* lds, u32& total) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    u32 inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    lds_barrier();
+    if (lane == 63) lds[wave] = inc;
+    lds_barrier();
+    u32 base = 0, sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32 t = lds[i];
+        if (i < wave) base += t;
+        sum += t;
+    }
+    total = sum;
+    return base + inc - v;
+}
+
 // ---- restart intervals -------------------------------------------------------------------
 // The unstuffed stream holds, per interval, an RSTn marker (every interval but the image's
 // first) and the interval's bit string padded to a whole byte; the band that ends the
@@ -779,25 +808,33 @@ __device__ __forceinline__ u32 ff_bits(u32 w) {   // bit k: byte k of w is 0xFF
 // Loads 16 stream bytes (plus one of lookahead) and returns a 16-bit mask of the data bytes
 // equal to 0xFF, i.e. those that need a 0x00 behind them (BitBuffer.cpp:156-161, 171-176,
 // 190-195).  Only bytes of the stream count.
+// noMarkers: the caller knows that none of these bytes begins a marker (the counting pass found
+// none in the chunk), which saves the look-up of the interval.  *foundMarker is set when one does.
 __device__ __forceinline__ u32 stuff_mask(const KGeom& g, const uint8_t* __restrict__ buf,
-                                          const u64* __restrict__ ivOff, u64 bytes, long long i0, uint4& q) {
-    q = *(const uint4*)(buf + i0);
+                                          const u64* __restrict__ ivOff, u64 bytes, long long i0, const uint4& q,
+                                          bool noMarkers = false, bool* foundMarker = nullptr) {
     u32 ff = ff_bits(q.x) | (ff_bits(q.y) << 4) | (ff_bits(q.z) << 8) | (ff_bits(q.w) << 12);
     const long long left = (long long)bytes - i0;
     if (left < 16) ff &= left > 0 ? (1u << (int)left) - 1u : 0u;
-    if (ff == 0) return 0;
+    if (ff == 0 || noMarkers) return ff;
     // One round per 0xFF byte of the piece (one or two as a rule) instead of one per byte.
     const u64 lo = (u64)q.x | ((u64)q.y << 32), hi = (u64)q.z | ((u64)q.w << 32);
-    const u32 last = (u32)buf[i0 + 16];
     u32 mask = ff;
     for (u32 todo = ff; todo != 0; todo &= todo - 1) {
         const int j = __builtin_ctz(todo), n = j + 1;
-        const uint8_t nxt = (uint8_t)(n < 8 ? lo >> (8 * n) : (n < 16 ? hi >> (8 * (n - 8)) : (u64)last));
+        const uint8_t nxt = (uint8_t)(n < 8 ? lo >> (8 * n) : (n < 16 ? hi >> (8 * (n - 8)) : (u64)buf[i0 + 16]));
         const bool maybe = (nxt >= 0xd0 && nxt <= 0xd7) || nxt == 0xd9;
-        if (maybe && is_marker_ff(g, ivOff, bytes, (u64)(i0 + j), nxt)) mask &= ~(1u << j);
+        if (maybe && is_marker_ff(g, ivOff, bytes, (u64)(i0 + j), nxt)) {
+            mask &= ~(1u << j);
+            if (foundMarker) *foundMarker = true;
+        }
     }
     return mask;
 }
+
+// What the counting pass leaves per chunk: the number of stuffing bytes, and in the top bit
+// whether a marker begins inside the chunk.
+constexpr u32 kChunkHasMarker = 0x80000000u;
 
 // One wave per 4 KiB chunk: four 16-byte pieces per lane in flight, a shuffle reduction, no
 // barriers.
@@ -811,17 +848,23 @@ __global__ __launch_bounds__(256) void k_count_ff(KGeom g, const uint8_t* __rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (long long ch = (long long)blockIdx.x * 4 + wave; ch < chunks; ch += (long long)gridDim.x * 4) {
         int cnt = 0;
+        bool marker = false;
+        uint4 q[kStuffChunk / 1024];
 #pragma unroll
         for (int k = 0; k < kStuffChunk / 1024; ++k) {
             const long long i0 = ch * kStuffChunk + k * 1024 + lane * 16;
-            if ((u64)i0 < bytes) {
-                uint4 q;
-                cnt += __popc(stuff_mask(g, buf, ivOff, bytes, i0, q));
-            }
+            q[k] = make_uint4(0, 0, 0, 0);
+            if ((u64)i0 < bytes) q[k] = *(const uint4*)(buf + i0);
+        }
+#pragma unroll
+        for (int k = 0; k < kStuffChunk / 1024; ++k) {
+            const long long i0 = ch * kStuffChunk + k * 1024 + lane * 16;
+            if ((u64)i0 < bytes) cnt += __popc(stuff_mask(g, buf, ivOff, bytes, i0, q[k], false, &marker));
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
-        if (lane == 0) ffCount[ch] = (u32)cnt;
+        const bool anyMarker = __ballot(marker) != 0;
+        if (lane == 0) ffCount[ch] = (u32)cnt | (anyMarker ? kChunkHasMarker : 0u);
     }
 }
 
@@ -834,7 +877,7 @@ __global__ __launch_bounds__(256) void k_group_sums(const u32* __restrict__ ffCo
     const long long grp = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (grp * kChunkGroup >= chunks) return;
     const long long c = grp * kChunkGroup + lane;
-    u64 sum = c < chunks ? ffCount[c] : 0;
+    u64 sum = c < chunks ? ffCount[c] & ~kChunkHasMarker : 0;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
     if (lane == 0) groupSum[grp] = sum;
@@ -850,14 +893,14 @@ __device__ __forceinline__ u64 chunk_prefix(const u64* __restrict__ groupSum, co
         const long long grp = ch / kChunkGroup;
         for (long long i = threadIdx.x; i < grp; i += 256) v += groupSum[i];
         const long long c = grp * kChunkGroup + threadIdx.x;
-        if (threadIdx.x < kChunkGroup && c < ch) v += ffCount[c];
+        if (threadIdx.x < kChunkGroup && c < ch) v += ffCount[c] & ~kChunkHasMarker;
     } else {
         // Eight loads in flight per thread: one after the other they would cost a memory
         // latency each.
         for (long long i0 = threadIdx.x; i0 < ch; i0 += 8 * 256) {
             u32 t[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = i0 + k * 256 < ch ? ffCount[i0 + k * 256] : 0u;
+            for (int k = 0; k < 8; ++k) t[k] = i0 + k * 256 < ch ? ffCount[i0 + k * 256] & ~kChunkHasMarker : 0u;
 #pragma unroll
             for (int k = 0; k < 8; ++k) v += t[k];
         }
@@ -869,11 +912,11 @@ __device__ __forceinline__ u64 chunk_prefix(const u64* __restrict__ groupSum, co
 }
 
 // Copies the stream to the output with the stuffing bytes inserted.  A workgroup's 4 KiB
-// chunk becomes one contiguous output range, which is laid out in LDS at the output's own
-// 4-byte phase and stored as dwords.  In a batch the stream of image k goes behind header k
-// in slot k; a chunk that holds the end of one image and the start of the next is written
-// byte by byte instead.
-constexpr int kStuffStageBytes = 2 * kStuffChunk + 16;
+// chunk becomes one contiguous output range; every lane builds the output of its sixteen
+// bytes in registers and stores it as dwords at the output's own 4-byte phase (a stage in LDS
+// that the lanes fill byte by byte costs the kernel half its time).  In a batch the stream of
+// image k goes behind header k in slot k; a chunk that holds the end of one image and the
+// start of the next is written byte by byte instead.
 
 // Interval (= image of a batch) that contains stream byte i.
 __device__ __forceinline__ long long interval_of(const KGeom& g, const u64* __restrict__ ivOff, u64 i) {
@@ -898,7 +941,6 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
                                                      uint8_t* __restrict__ out, long long prefixLen,
                                                      long long outCapacity, BatchOutput bo, u64* __restrict__ hostResult) {
     __shared__ u64 lds[4];
-    __shared__ __attribute__((aligned(16))) uint8_t stage[kStuffStageBytes];
     const u64 bytes = result[2];
     const long long chunks = (long long)((bytes + kStuffChunk - 1) / kStuffChunk);
     // A workgroup takes a run of consecutive chunks: the stuffing bytes in front of the
@@ -913,19 +955,36 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
         hostResult[3] = result[1] & ~1ull;
     }
     if (chFirst >= chEnd) return;
+    // A chunk's bytes (sixteen per lane and the four behind them) are asked for while the chunk in
+    // front of it is worked on.
+    __shared__ u32 scanLds[4];
+    uint4 qNext = make_uint4(0, 0, 0, 0);
+    u32 eNext = 0, flagsNext = 0;
+    auto fetch = [&](long long ch) {
+        const long long i0 = ch * kStuffChunk + (long long)threadIdx.x * 16;
+        qNext = make_uint4(0, 0, 0, 0);
+        eNext = 0;
+        if ((u64)i0 < bytes) qNext = *(const uint4*)(buf + i0);
+        if ((u64)i0 + 16 < bytes) eNext = *(const u32*)(buf + i0 + 16);
+        // does a marker begin in this chunk, or (bit 1) in the next one, where the last lane's four bytes lie
+        flagsNext = (ffCount[ch] >> 31) | (ch + 1 < chunks ? (ffCount[ch + 1] >> 31) << 1 : 0u);
+    };
+    fetch(chFirst);
     u64 ffBefore = chunk_prefix(groupSum, ffCount, chFirst, lds);
     for (long long ch = chFirst; ch < chEnd; ++ch) {
         const long long c0 = ch * kStuffChunk;
         const long long i0 = c0 + (long long)threadIdx.x * 16;
-        uint4 q = make_uint4(0, 0, 0, 0);
+        const uint4 q = qNext;
+        const u32 e = eNext, flags = flagsNext;
+        if (ch + 1 < chEnd) fetch(ch + 1);
         int valid = 0;
         u32 mask = 0;
         if ((u64)i0 < bytes) {
             valid = (int)(bytes - (u64)i0 < 16 ? bytes - (u64)i0 : 16);
-            mask = stuff_mask(g, buf, ivOff, bytes, i0, q);
+            mask = stuff_mask(g, buf, ivOff, bytes, i0, q, (flags & 1u) == 0);
         }
-        u64 total;
-        const u64 local = block_exclusive_scan((u64)(valid + __popc(mask)), lds, total);
+        u32 total;
+        const u32 local = block_exclusive_scan_lds((u32)(valid + __popc(mask)), scanLds, total);
         // Output range of the chunk: one piece, except for a batch chunk that spans images.
         long long base, limit;
         bool onePiece = true;
@@ -945,31 +1004,53 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
                     atomicOr((unsigned long long*)&result[1], 1ull);
                     if (hostResult) hostResult[1] = 1;
                 }
-            } else {
-                const int phase = (int)((uintptr_t)(out + base) & 3);
-                if (valid > 0) {
-                    uint8_t* dst = stage + phase + (int)local;
-                    const u32 ws[4] = {q.x, q.y, q.z, q.w};
-                    if (mask == 0 && valid == 16) {
+            } else if (valid > 0) {
+                // The lane's output as a string of bytes in registers: its sixteen bytes, then the
+                // four that follow them in the stream (the lane owns every output dword that
+                // begins among its own bytes, and such a dword may end among its successor's),
+                // with a zero byte inserted behind every 0xFF that is data.
+                u32 str[9] = {q.x, q.y, q.z, q.w, 0u, 0u, 0u, 0u, 0u};
+                u32 todo = mask;
+                if ((u64)i0 + 16 < bytes) {
+                    str[4] = e;
+                    u32 ef = ff_bits(e) & 7u;
+                    const bool mayHold = (flags >> (threadIdx.x == 255 ? 1 : 0)) & 1u;   // a marker may begin among these bytes
+                    for (u32 t = ef; t != 0; t &= t - 1) {
+                        const int j = __builtin_ctz(t);
+                        const uint8_t nxt = (uint8_t)(e >> (8 * (j + 1)));
+                        if ((u64)i0 + 16 + j >= bytes || (mayHold && is_marker_ff(g, ivOff, bytes, (u64)(i0 + 16 + j), nxt))) ef &= ~(1u << j);
+                    }
+                    todo |= ef << 16;
+                }
+                for (u32 inserted = 0; todo != 0; todo &= todo - 1, ++inserted) {
+                    const u32 z = (u32)__builtin_ctz(todo) + inserted + 1;   // index the zero byte gets
+                    const u32 w = z >> 2, r = z & 3u;
+                    const u32 keep = (1u << (8 * r)) - 1u, above = 0xffffff00u << (8 * r);
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) dst[j] = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
-                    } else {
-                        int o = 0;
-                        for (int j = 0; j < valid; ++j) {
-                            dst[o++] = (uint8_t)(ws[j >> 2] >> ((j & 3) * 8));
-                            if ((mask >> j) & 1) dst[o++] = 0x00;
-                        }
+                    for (int i = 8; i >= 0; --i) {   // bytes from z on move up by one
+                        const u32 up = i > 0 ? __builtin_amdgcn_alignbyte(str[i], str[i > 0 ? i - 1 : 0], 3) : str[0] << 8;
+                        if ((u32)i > w) str[i] = up;
+                        else if ((u32)i == w) str[i] = (str[i] & keep) | (up & above);
                     }
                 }
-                __syncthreads();
-                const int nTot = phase + (int)total;
-                uint8_t* dst = out + base - phase;   // 4-byte aligned
-                for (int d = threadIdx.x; d * 4 < nTot; d += 256) {
-                    const int lo4 = d * 4;
-                    if (lo4 >= phase && lo4 + 4 <= nTot) {
-                        *(u32*)(dst + lo4) = *(const u32*)(stage + lo4);
-                    } else {
-                        for (int bb = lo4 < phase ? phase : lo4; bb < lo4 + 4 && bb < nTot; ++bb) dst[bb] = stage[bb];
+                const u32 nOut = (u32)valid + (u32)__popc(mask);
+                const long long mine = base + (long long)local, chunkEnd = base + (long long)total;
+                uint8_t* dst = out + mine;
+                const u32 a = (u32)(-(long long)(uintptr_t)dst) & 3u;   // bytes in front of the first dword that begins here
+                // The chunk's first bytes up to a dword boundary (the dword belongs to another
+                // chunk, or to the header): byte by byte.
+                if (threadIdx.x == 0)
+                    for (u32 b = 0; b < a && b < nOut; ++b) dst[b] = (uint8_t)(str[0] >> (8 * b));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const u32 off = a + 4u * i;
+                    if (off < nOut) {
+                        const u32 v = __builtin_amdgcn_alignbyte(str[i + 1], str[i], a);
+                        if (mine + off + 4 <= chunkEnd) {
+                            *(u32*)(dst + off) = v;
+                        } else {   // the chunk ends inside this dword
+                            for (u32 b = 0; mine + off + b < chunkEnd; ++b) dst[off + b] = (uint8_t)(v >> (8 * b));
+                        }
                     }
                 }
             }
@@ -1003,7 +1084,6 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
         }
         const u64 chunkBytes = bytes - (u64)c0 < (u64)kStuffChunk ? bytes - (u64)c0 : (u64)kStuffChunk;
         ffBefore += total - chunkBytes;   // what the chunk wrote beyond its own bytes
-        __syncthreads();
     }
 }
 
@@ -1020,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_image_ff_start(KGeom g, const uint8_t* 
     const long long i0 = ch * kStuffChunk + (long long)threadIdx.x * 16;
     int cnt = 0;
     if ((u64)i0 < pos) {
-        uint4 q;
+        const uint4 q = *(const uint4*)(buf + i0);
         u32 mask = stuff_mask(g, buf, ivOff, bytes, i0, q);
         const u64 span = pos - (u64)i0;
         if (span < 16) mask &= (1u << span) - 1u;
@@ -1083,12 +1163,16 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     // The bit writer ORs into the stream, so the part it can reach starts out as zeros.
     long long zero = ws.streamBound < 0 ? ws.unstuffedCap : (ws.streamBound + kStuffChunk + 63) / 16 * 16;
     if (zero > ws.unstuffedCap) zero = ws.unstuffedCap;
-    long long prepGrid = zero / 16 / (256 * 4);
+    // (Not when the tiles' bits are placed by k_place_tiles and k_merge_edges: those write every
+    // word of the stream exactly once, with plain stores.)
+    const bool deferred = !fromRecords && groups && ws.tileSlots != nullptr && ws.groupTile == kGrpTileBlocks;
+    const long long clear16 = deferred ? 0 : zero / 16;
+    long long prepGrid = (clear16 > tileCount / 2 ? clear16 : tileCount / 2) / (256 * 4);
     prepGrid = prepGrid < 1 ? 1 : (prepGrid > 2048 ? 2048 : prepGrid);
     // Chunks the stream can have at most: from the bound that was cleared.
     long long chunkBound = zero / kStuffChunk + 1;
     if (chunkBound > ws.maxChunks) chunkBound = ws.maxChunks;
-    hipLaunchKernelGGL(k_prepare_entropy, dim3((unsigned)prepGrid), dim3(256), 0, s, (uint4*)ws.unstuffed, zero / 16,
+    hipLaunchKernelGGL(k_prepare_entropy, dim3((unsigned)prepGrid), dim3(256), 0, s, (uint4*)ws.unstuffed, clear16,
                        ws.tileState, tileCount + 1, ws.result, ws.header, bo ? 0 : ws.headerLen, d_out,
                        bo ? nullptr : ws.pendingTables, const_cast<u32*>(d_tables));
     // Long blocks (noise, q=100) do not fit the private words; unknown lengths count as short.
@@ -1105,7 +1189,7 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
                            ws.recCount, ws.recGeneration, d_tables, ws.tileState, runStart, ws.ivOff, ws.result,
                            (u32*)ws.unstuffed, zero);
     }
-    else if (groups && ws.tileSlots != nullptr && ws.groupTile == kGrpTileBlocks) {
+    else if (deferred) {
         // Nobody waits: the tiles leave their bits in slots, two small kernels find where every
         // tile starts, a third puts the bits there (a tile that chains with a look-back spends a
         // quarter of its life waiting for the slowest of the thousands of tiles in front of it).
@@ -1128,7 +1212,12 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     else
         hipLaunchKernelGGL(k_encode_bits<false>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
                            ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult, zero);
-    long long chunkGrid = chunkBound < 4096 ? chunkBound : 4096;
+    // As many workgroups as the device holds at once (five per CU): a workgroup's run of chunks is
+    // one chain (a chunk's bytes are asked for while the chunk in front is worked on), a second
+    // round of workgroups would start that chain all over.  (Diagnostic switch JPEGENC_STUFF_GRID.)
+    static const long long gridCap = getenv("JPEGENC_STUFF_GRID") ? atoll(getenv("JPEGENC_STUFF_GRID")) : 1280;
+
+    long long chunkGrid = chunkBound < gridCap ? chunkBound : gridCap;
     if (chunkGrid < 1) chunkGrid = 1;
     long long countGrid = (chunkBound + 3) / 4;
     countGrid = countGrid < 1 ? 1 : (countGrid > 4096 ? 4096 : countGrid);
