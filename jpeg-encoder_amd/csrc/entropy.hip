@@ -307,6 +307,27 @@ __device__ __forceinline__ u32 block_exclusive_scan_lds(u32 v, u32* lds, u32& to
     return base + inc - v;
 }
 
+// Per 4 KiB chunk of the unstuffed stream, ffCount holds the number of stuffing bytes the chunk
+// needs (its 0xFF bytes that are data) in the low half and the number of markers that begin in it
+// in the high half.  Either the counting pass writes the word, or the kernels that place the bits
+// add to it (a marker's 0xFF is counted like any other byte there and taken off again where the
+// marker is known: kChunkMarkerDelta does both; the sums are exact once all have been added).
+constexpr u32 kChunkCountMask = 0xffffu;
+constexpr u32 kChunkMarkerOne = 0x10000u;
+constexpr u32 kChunkMarkerDelta = kChunkMarkerOne - 1u;
+constexpr int kChunkWordShift = 10;   // stream words per chunk: 1024
+static_assert(kStuffChunk == 4 << kChunkWordShift, "a chunk is 1024 words");
+
+__device__ __forceinline__ u32 ff_bits(u32 w) {   // bit k: byte k of w is 0xFF
+    u32 t = w & (w >> 4);
+    t &= t >> 2;
+    t &= t >> 1;
+    // The flags sit at bits 0, 8, 16, 24; the product brings them to bits 24..27 (no two of
+    // the sixteen partial products meet, so nothing carries).
+    return ((t & 0x01010101u) * 0x01020408u) >> 24;
+}
+
+
 // ---- restart intervals -------------------------------------------------------------------
 // The unstuffed stream holds, per interval, an RSTn marker (every interval but the image's
 // first) and the interval's bit string padded to a whole byte; the band that ends the
@@ -796,15 +817,6 @@ __device__ __forceinline__ bool is_marker_ff(const KGeom& g, const u64* __restri
     return ivOff[lo] == i && interval_marker_bytes(g, lo) != 0;
 }
 
-__device__ __forceinline__ u32 ff_bits(u32 w) {   // bit k: byte k of w is 0xFF
-    u32 t = w & (w >> 4);
-    t &= t >> 2;
-    t &= t >> 1;
-    // The flags sit at bits 0, 8, 16, 24; the product brings them to bits 24..27 (no two of
-    // the sixteen partial products meet, so nothing carries).
-    return ((t & 0x01010101u) * 0x01020408u) >> 24;
-}
-
 // Loads 16 stream bytes (plus one of lookahead) and returns a 16-bit mask of the data bytes
 // equal to 0xFF, i.e. those that need a 0x00 behind them (BitBuffer.cpp:156-161, 171-176,
 // 190-195).  Only bytes of the stream count.
@@ -831,10 +843,6 @@ __device__ __forceinline__ u32 stuff_mask(const KGeom& g, const uint8_t* __restr
     }
     return mask;
 }
-
-// What the counting pass leaves per chunk: the number of stuffing bytes, and in the top bit
-// whether a marker begins inside the chunk.
-constexpr u32 kChunkHasMarker = 0x80000000u;
 
 // One wave per 4 KiB chunk: four 16-byte pieces per lane in flight, a shuffle reduction, no
 // barriers.
@@ -864,7 +872,7 @@ __global__ __launch_bounds__(256) void k_count_ff(KGeom g, const uint8_t* __rest
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
         const bool anyMarker = __ballot(marker) != 0;
-        if (lane == 0) ffCount[ch] = (u32)cnt | (anyMarker ? kChunkHasMarker : 0u);
+        if (lane == 0) ffCount[ch] = (u32)cnt | (anyMarker ? kChunkMarkerOne : 0u);
     }
 }
 
@@ -877,7 +885,7 @@ __global__ __launch_bounds__(256) void k_group_sums(const u32* __restrict__ ffCo
     const long long grp = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (grp * kChunkGroup >= chunks) return;
     const long long c = grp * kChunkGroup + lane;
-    u64 sum = c < chunks ? ffCount[c] & ~kChunkHasMarker : 0;
+    u64 sum = c < chunks ? ffCount[c] & kChunkCountMask : 0;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
     if (lane == 0) groupSum[grp] = sum;
@@ -893,14 +901,14 @@ __device__ __forceinline__ u64 chunk_prefix(const u64* __restrict__ groupSum, co
         const long long grp = ch / kChunkGroup;
         for (long long i = threadIdx.x; i < grp; i += 256) v += groupSum[i];
         const long long c = grp * kChunkGroup + threadIdx.x;
-        if (threadIdx.x < kChunkGroup && c < ch) v += ffCount[c] & ~kChunkHasMarker;
+        if (threadIdx.x < kChunkGroup && c < ch) v += ffCount[c] & kChunkCountMask;
     } else {
         // Eight loads in flight per thread: one after the other they would cost a memory
         // latency each.
         for (long long i0 = threadIdx.x; i0 < ch; i0 += 8 * 256) {
             u32 t[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = i0 + k * 256 < ch ? ffCount[i0 + k * 256] & ~kChunkHasMarker : 0u;
+            for (int k = 0; k < 8; ++k) t[k] = i0 + k * 256 < ch ? ffCount[i0 + k * 256] & kChunkCountMask : 0u;
 #pragma unroll
             for (int k = 0; k < 8; ++k) v += t[k];
         }
@@ -967,7 +975,7 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
         if ((u64)i0 < bytes) qNext = *(const uint4*)(buf + i0);
         if ((u64)i0 + 16 < bytes) eNext = *(const u32*)(buf + i0 + 16);
         // does a marker begin in this chunk, or (bit 1) in the next one, where the last lane's four bytes lie
-        flagsNext = (ffCount[ch] >> 31) | (ch + 1 < chunks ? (ffCount[ch + 1] >> 31) << 1 : 0u);
+        flagsNext = (ffCount[ch] > kChunkCountMask ? 1u : 0u) | (ch + 1 < chunks && ffCount[ch + 1] > kChunkCountMask ? 2u : 0u);
     };
     fetch(chFirst);
     u64 ffBefore = chunk_prefix(groupSum, ffCount, chFirst, lds);
@@ -1129,8 +1137,10 @@ __global__ __launch_bounds__(256) void k_prepare_entropy(uint4* __restrict__ str
                                                          u64* __restrict__ tileState, long long tileWords,
                                                          u64* __restrict__ result, const uint8_t* __restrict__ hdr,
                                                          int hdrLen, uint8_t* __restrict__ out,
-                                                         const u32* __restrict__ pending, u32* __restrict__ tables) {
+                                                         const u32* __restrict__ pending, u32* __restrict__ tables,
+                                                         u32* __restrict__ ffCount, long long ffWords) {
     const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, step = (long long)gridDim.x * 256;
+    for (long long i = tid; i < ffWords; i += step) ffCount[i] = 0;   // (when the placing kernels count the 0xFF bytes)
     if (pending != nullptr) {
         // Tables and header still sit in pinned host memory: bring them over (the device
         // copy serves later launches) and take the header for the output from there.
@@ -1174,7 +1184,7 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     if (chunkBound > ws.maxChunks) chunkBound = ws.maxChunks;
     hipLaunchKernelGGL(k_prepare_entropy, dim3((unsigned)prepGrid), dim3(256), 0, s, (uint4*)ws.unstuffed, clear16,
                        ws.tileState, tileCount + 1, ws.result, ws.header, bo ? 0 : ws.headerLen, d_out,
-                       bo ? nullptr : ws.pendingTables, const_cast<u32*>(d_tables));
+                       bo ? nullptr : ws.pendingTables, const_cast<u32*>(d_tables), ws.ffCount, deferred ? chunkBound : 0);
     // Long blocks (noise, q=100) do not fit the private words; unknown lengths count as short.
     const bool shortBlocks = ws.avgBlockBits <= 128;
     if (fromRecords) {
@@ -1200,9 +1210,9 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
         hipLaunchKernelGGL(k_group_positions, dim3(runs), dim3(64), 0, s, ws.tileState, runStart, (u32)tileCount);
         hipLaunchKernelGGL(k_run_positions, dim3(1), dim3(1024), 0, s, g, runStart, runs);
         hipLaunchKernelGGL(k_place_tiles, dim3((unsigned)((tileCount + 3) / 4)), dim3(256), 0, s, g, ws.tileState, runStart,
-                           ws.tileSlots, ws.ivOff, ws.result, (u32*)ws.unstuffed, (u32)tileCount, zero);
+                           ws.tileSlots, ws.ivOff, ws.result, (u32*)ws.unstuffed, (u32)tileCount, zero, ws.ffCount);
         hipLaunchKernelGGL(k_merge_edges, dim3((unsigned)((4 * tileCount + 255) / 256)), dim3(256), 0, s, g, ws.tileSlots,
-                           (u32*)ws.unstuffed, (u32)tileCount);
+                           (u32*)ws.unstuffed, (u32)tileCount, ws.ffCount);
     } else if (groups)
         hipLaunchKernelGGL(k_encode_groups<false>, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, d_coef, d_tables, ws.tileState,
                            ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero, nullptr);
@@ -1221,8 +1231,10 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     if (chunkGrid < 1) chunkGrid = 1;
     long long countGrid = (chunkBound + 3) / 4;
     countGrid = countGrid < 1 ? 1 : (countGrid > 4096 ? 4096 : countGrid);
-    hipLaunchKernelGGL(k_count_ff, dim3((unsigned)countGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.result,
-                       ws.ffCount);
+    // (With deferred placement the placing kernels have counted the 0xFF bytes as they wrote them.)
+    if (!deferred)
+        hipLaunchKernelGGL(k_count_ff, dim3((unsigned)countGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.result,
+                           ws.ffCount);
     // Up to this many chunks a workgroup adds the counts in front of its first chunk up
     // directly (64 loads per thread at most); beyond, group sums come first.
     const u64* groupSum = nullptr;

@@ -313,8 +313,10 @@ constexpr u64 kNoEdge = ~0ull;
 
 // padN one bits at bit position padAt (the padding behind an interval end, when it is made of ones)
 // are merged into the word they fall into, which is the range's last.
+// ffCount (may be null): the 0xFF bytes of the words written here are added to their chunks'
+// counts (see kChunkCountMask); the words at the edges are counted by k_merge_edges.
 __device__ __forceinline__ void slot_place(u32 (&lo)[kSlotCopyRounds], u32 bits, u64 dst, u32* __restrict__ words,
-                                           u64* __restrict__ edge, u64 padAt = 0, u32 padN = 0) {
+                                           u64* __restrict__ edge, u32* __restrict__ ffCount, u64 padAt = 0, u32 padN = 0) {
     const int lane = threadIdx.x & 63;
     if (bits == 0) {
         if (lane == 0) edge[0] = edge[1] = kNoEdge;
@@ -327,6 +329,9 @@ __device__ __forceinline__ void slot_place(u32 (&lo)[kSlotCopyRounds], u32 bits,
     for (int k = 0; k < kSlotCopyRounds; ++k)
         if ((u32)lane + 64u * k >= nSrc) lo[k] = 0;
     if (lane == 0 && nOut == 1) edge[1] = kNoEdge;
+    // A part is shorter than a chunk: its words lie in the chunk of its first word or in the next.
+    const u64 firstChunk = w0 >> kChunkWordShift;
+    u32 ffHere = 0, ffNext = 0;
 #pragma unroll
     for (int k = 0; k < kSlotCopyRounds; ++k) {
         const u32 i = (u32)lane + 64u * k;
@@ -338,16 +343,30 @@ __device__ __forceinline__ void slot_place(u32 (&lo)[kSlotCopyRounds], u32 bits,
             if (padN != 0 && w0 + i == (padAt >> 5)) v |= __builtin_bswap32(((1u << padN) - 1u) << (32u - (u32)(padAt & 31) - padN));
             if (i == 0) edge[0] = ((w0 + i) << 32) | v;
             else if (i == nOut - 1) edge[1] = ((w0 + i) << 32) | v;
-            else words[w0 + i] = v;
+            else {
+                words[w0 + i] = v;
+                const u32 n = (u32)__popc(ff_bits(v));
+                if (((w0 + i) >> kChunkWordShift) == firstChunk) ffHere += n; else ffNext += n;
+            }
+        }
+    }
+    if (ffCount != nullptr) {
+        // counts of at most 4 * 11 per lane: both sums travel in one register
+        u32 both = ffHere | (ffNext << 16);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) both += (u32)__shfl_xor((int)both, d, 64);
+        if (lane == 0) {
+            if ((both & 0xffffu) != 0) atomicAdd(&ffCount[firstChunk], both & 0xffffu);
+            if ((both >> 16) != 0) atomicAdd(&ffCount[firstChunk + 1], both >> 16);
         }
     }
 }
 
 __device__ __forceinline__ void slot_copy_out(const u32* __restrict__ slot, u32 srcWord, u32 bits, u64 dst,
-                                              u32* __restrict__ words, u64* __restrict__ edge) {
+                                              u32* __restrict__ words, u64* __restrict__ edge, u32* __restrict__ ffCount) {
     u32 lo[kSlotCopyRounds];
     slot_load(slot, srcWord, lo);
-    slot_place(lo, bits, dst, words, edge);
+    slot_place(lo, bits, dst, words, edge, ffCount);
 }
 
 // What a tile leaves behind when its bits are placed by a later kernel (k_place_tiles): the
@@ -359,7 +378,8 @@ static_assert(kGrpMaxFix == 24, "the slot's size is written out above");
 template <bool kClear>
 __device__ __forceinline__ void place_tile(const KGeom& g, u32* st, PosSummary whole, u64 start, u32 nFix, const u32* fixBlock,
                                            const u32* fixRel, u32 image, u64* __restrict__ ivOff, u64* __restrict__ result,
-                                           u32* __restrict__ words, long long zeroedBytes, u32 partWord = ~0u) {
+                                           u32* __restrict__ words, long long zeroedBytes, u32 partWord = ~0u,
+                                           u32* __restrict__ ffCount = nullptr) {
     // partWord: word of the stage at which the part behind the first interval end starts (given
     // by a caller that has placed the part in front of it already and passes h = 0 with its end as `start`).
     const int lane = threadIdx.x & 63;
@@ -368,11 +388,11 @@ __device__ __forceinline__ void place_tile(const KGeom& g, u32* st, PosSummary w
     if (!frontDone) partWord = (((h + 31u) & ~31u) + 32u) >> 5;
     u64* edges = (u64*)(st + kGrpSlotEdges);   // (slots only)
     if (kClear) stage_copy_out<true>(st, 0, h, start, words);   // (kClear: the stage in LDS; otherwise a slot in memory)
-    else if (!frontDone) slot_copy_out(st, 0, h, start, words, edges);
+    else if (!frontDone) slot_copy_out(st, 0, h, start, words, edges, ffCount);
     if (whole.x >> 31) {
         const u64 partStart = (start + h + 7) & ~7ull;
         if (kClear) stage_copy_out<true>(st, partWord, whole.y, partStart, words);
-        else slot_copy_out(st, partWord, whole.y, partStart, words, edges + 2);
+        else slot_copy_out(st, partWord, whole.y, partStart, words, edges + 2, ffCount);
         if (kClear && g.padOnes && partStart != start + h && lane == 0) {   // the first end's padding, as one bits (slots: see slot_place)
             const u64 at = start + h;
             const u32 nPad = (u32)(partStart - at);
@@ -383,6 +403,13 @@ __device__ __forceinline__ void place_tile(const KGeom& g, u32* st, PosSummary w
             const long long iv = g.batch > 1 ? (long long)image : (long long)((bl / (u32)g.bpm) / (u32)g.mcusPerInterval);
             const u64 bytes = (partStart + fixRel[lane]) >> 3;
             ivOff[iv + 1] = bytes;
+            if (!kClear && ffCount != nullptr) {
+                // The markers at this interval's end are no data: EOI in front of `bytes` (the image
+                // ends), or the next interval's RSTn at `bytes`.
+                const bool lastOne = g.batch > 1 || iv + 1 == g.intervals;
+                if (g.writeEoi && lastOne) atomicAdd(&ffCount[(bytes - 2) >> 12], kChunkMarkerDelta);
+                if (g.batch == 1 && !lastOne) atomicAdd(&ffCount[bytes >> 12], kChunkMarkerDelta);
+            }
             if (iv + 1 == g.intervals) {
                 result[2] = bytes;
                 result[3] = (bytes + kStuffChunk - 1) / kStuffChunk;
@@ -680,7 +707,8 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
 // (k_group_positions, k_run_positions).
 __global__ __launch_bounds__(256) void k_place_tiles(KGeom g, const u64* __restrict__ state, const u64* __restrict__ runStart,
                                                      u32* __restrict__ slots, u64* __restrict__ ivOff, u64* __restrict__ result,
-                                                     u32* __restrict__ words, u32 tiles, long long zeroedBytes) {
+                                                     u32* __restrict__ words, u32 tiles, long long zeroedBytes,
+                                                     u32* __restrict__ ffCount) {
     const int lane = threadIdx.x & 63;
     const u32 tile = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (tile >= tiles) return;
@@ -699,12 +727,13 @@ __global__ __launch_bounds__(256) void k_place_tiles(KGeom g, const u64* __restr
     u64* edges = (u64*)(slot + kGrpSlotEdges);
     const u64 at = start + h;
     const u32 padN = (whole.x >> 31) && g.padOnes ? (u32)(((at + 7) & ~7ull) - at) : 0u;
-    slot_place(lo, h, start, words, edges, at, padN);
+    slot_place(lo, h, start, words, edges, ffCount, at, padN);
     if ((whole.x >> 31) == 0) {
         if (lane == 0) edges[2] = edges[3] = kNoEdge;
     } else {
         place_tile<false>(g, slot, PosSummary{0x80000000u, whole.y}, at, nFix, slot + kGrpSlotHead + 4,
-                          slot + kGrpSlotHead + 4 + kGrpMaxFix, image, ivOff, result, words, zeroedBytes, (((h + 31u) & ~31u) + 32u) >> 5);
+                          slot + kGrpSlotHead + 4 + kGrpMaxFix, image, ivOff, result, words, zeroedBytes, (((h + 31u) & ~31u) + 32u) >> 5,
+                          ffCount);
     }
     if (tile == 0 && lane == 0) ivOff[0] = 0;
 }
@@ -712,7 +741,8 @@ __global__ __launch_bounds__(256) void k_place_tiles(KGeom g, const u64* __restr
 // The stream words at the edges of the tiles' parts: entries with the same word number are
 // ORed together (neighbours meet inside a word) and the first of such a run writes the word.
 // A band that does not begin the image starts with the RSTn of the interval in front of it.
-__global__ __launch_bounds__(256) void k_merge_edges(KGeom g, const u32* __restrict__ slots, u32* __restrict__ words, u32 tiles) {
+__global__ __launch_bounds__(256) void k_merge_edges(KGeom g, const u32* __restrict__ slots, u32* __restrict__ words, u32 tiles,
+                                                     u32* __restrict__ ffCount) {
     const long long n = 4ll * tiles;
     const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
     auto entry = [&](long long k) { return ((const u64*)(slots + (size_t)(k >> 2) * kGrpSlotWords + kGrpSlotEdges))[k & 3]; };
@@ -726,6 +756,8 @@ __global__ __launch_bounds__(256) void k_merge_edges(KGeom g, const u32* __restr
             v |= (u32)e;
         }
         words[0] = v;
+        // (the RSTn's own 0xFF is a marker's)
+        atomicAdd(&ffCount[0], (u32)__popc(ff_bits(v)) + kChunkMarkerDelta);
         return;
     }
     if (c >= n) return;
@@ -747,4 +779,6 @@ __global__ __launch_bounds__(256) void k_merge_edges(KGeom g, const u32* __restr
         v |= (u32)e;
     }
     words[w] = v;
+    const u32 ffs = (u32)__popc(ff_bits(v));
+    if (ffs != 0) atomicAdd(&ffCount[w >> kChunkWordShift], ffs);
 }
