@@ -141,32 +141,10 @@ struct HistVisitor {
     __device__ __forceinline__ void eob() { atomicAdd(&acHist[0], 1u); }
 };
 
-// blockIdx.y is the image of the batch; a workgroup never mixes images, so its LDS counts
-// belong to one histogram set.
-__global__ __launch_bounds__(kEntThreads) void k_histogram(KGeom g, const int16_t* __restrict__ coef,
-                                                           u64* __restrict__ hist, HistogramExport ex) {
-    __shared__ u32 lh[4 * 256];   // DC-Y, DC-C, AC-Y, AC-C (Encoder.cpp:368-416)
+// Adds a workgroup's 1024 counters in LDS (complete: the caller has passed a barrier) to the
+// image's histograms in memory, and hands the sums to the host when the export asks for it.
+__device__ __forceinline__ void flush_histograms(u32* lh, u64* __restrict__ hist, const HistogramExport& ex) {
     __shared__ bool lastOne;
-    for (int i = threadIdx.x; i < 1024; i += kEntThreads) lh[i] = 0;
-    __syncthreads();
-    const int16_t* image = coef + (long long)blockIdx.y * g.blocksPerImage * 64;
-    const u32 blocks = (u32)g.blocksPerImage;
-    const u32 stride = gridDim.x * kEntThreads;
-    for (u32 bl = blockIdx.x * kEntThreads + threadIdx.x; __any(bl < blocks); bl += stride) {
-        const bool active = bl < blocks;
-        const u32 cur = active ? bl : blocks - 1;   // lanes past the end stay in step for the shuffle
-        const BlockRole role = block_role(g, cur);
-        u32 w[32];
-        load_block(image, cur, w);
-        const int fetched = image[dc_predictor_source(role, cur) * 64];
-        const int pred = dc_predictor_lanes(role, coef_at(w, 0), fetched, active);
-        if (active) {
-            const int t = role.c == 0 ? 0 : 1;
-            HistVisitor vis{lh + 256 * t, lh + 512 + 256 * t};
-            walk_block(w, pred, vis);
-        }
-    }
-    __syncthreads();
     u64* mine = hist + (long long)blockIdx.y * 1024;
     if (ex.host == nullptr) {
         for (int i = threadIdx.x; i < 1024; i += kEntThreads)
@@ -198,6 +176,34 @@ __global__ __launch_bounds__(kEntThreads) void k_histogram(KGeom g, const int16_
         ex.host[i] = __hip_atomic_load(&hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// blockIdx.y is the image of the batch; a workgroup never mixes images, so its LDS counts
+// belong to one histogram set.
+__global__ __launch_bounds__(kEntThreads) void k_histogram(KGeom g, const int16_t* __restrict__ coef,
+                                                           u64* __restrict__ hist, HistogramExport ex) {
+    __shared__ u32 lh[4 * 256];   // DC-Y, DC-C, AC-Y, AC-C (Encoder.cpp:368-416)
+    for (int i = threadIdx.x; i < 1024; i += kEntThreads) lh[i] = 0;
+    __syncthreads();
+    const int16_t* image = coef + (long long)blockIdx.y * g.blocksPerImage * 64;
+    const u32 blocks = (u32)g.blocksPerImage;
+    const u32 stride = gridDim.x * kEntThreads;
+    for (u32 bl = blockIdx.x * kEntThreads + threadIdx.x; __any(bl < blocks); bl += stride) {
+        const bool active = bl < blocks;
+        const u32 cur = active ? bl : blocks - 1;   // lanes past the end stay in step for the shuffle
+        const BlockRole role = block_role(g, cur);
+        u32 w[32];
+        load_block(image, cur, w);
+        const int fetched = image[dc_predictor_source(role, cur) * 64];
+        const int pred = dc_predictor_lanes(role, coef_at(w, 0), fetched, active);
+        if (active) {
+            const int t = role.c == 0 ? 0 : 1;
+            HistVisitor vis{lh + 256 * t, lh + 512 + 256 * t};
+            walk_block(w, pred, vis);
+        }
+    }
+    __syncthreads();
+    flush_histograms(lh, hist, ex);
+}
+
 // Zeroes n 8-byte words.  A kernel rather than hipMemsetAsync: a launch costs the host a
 // few microseconds, a memset call several times that.
 __global__ __launch_bounds__(256) void k_zero_words(u64* __restrict__ p, long long n) {
@@ -210,6 +216,9 @@ hipError_t launch_clear_histograms(unsigned long long* d_hist, int images, hipSt
                        s, d_hist, words);
     return hipGetLastError();
 }
+
+static long long histogram_tiles_min_blocks();
+static hipError_t launch_histogram_tiles(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, HistogramExport* ex);
 
 hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, bool clear,
                             HistogramExport* ex) {
@@ -228,6 +237,13 @@ hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, 
     long long grid = (passes + rounds - 1) / rounds;
     if (grid < 1) grid = 1;
     HistogramExport none = {nullptr, 0, nullptr};
+    // Large images: one lane per group of eight coefficients that is not empty (k_histogram_tiles).
+    // (Diagnostic switch JPEGENC_HIST_FORM=1: always one lane per block.)
+    static const bool perBlock = getenv("JPEGENC_HIST_FORM") != nullptr && getenv("JPEGENC_HIST_FORM")[0] == '1';
+    if (!perBlock && g.groupMask != nullptr && g.blocksPerImage >= histogram_tiles_min_blocks()) {
+        const hipError_t e = launch_histogram_tiles(g, d_coef, d_hist, s, ex != nullptr && g.batch == 1 ? ex : nullptr);
+        return e;
+    }
     if (ex != nullptr && g.batch == 1) ex->expected += (unsigned long long)grid;   // what the counter reads when all are done
     hipLaunchKernelGGL(k_histogram, dim3((unsigned)grid, (unsigned)g.batch), dim3(kEntThreads), 0, s, g, d_coef, d_hist,
                        ex != nullptr && g.batch == 1 ? *ex : none);
@@ -542,6 +558,28 @@ __device__ __forceinline__ bool look_back(const u64* state, long long tile, u64 
 }
 
 #include "entropy_groups.h"
+
+// It pays from about a million blocks on (3840 x 2160 4:4:4, 0.39 million: 30 us against the 29 of
+// k_histogram; 8192 x 8192 4:2:0 noise, 1.6 million: 99 against 117; 16384 x 16384: 189 against 208).
+// (Diagnostic switch JPEGENC_HIST_TILES_MIN_BLOCKS: another threshold, read at every call so that a
+// test can set it.)
+static long long histogram_tiles_min_blocks() {
+    const char* env = getenv("JPEGENC_HIST_TILES_MIN_BLOCKS");
+    return env ? atoll(env) : 1000000;
+}
+
+static hipError_t launch_histogram_tiles(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, HistogramExport* ex) {
+    const long long tilesPerImage = (g.blocksPerImage + kHistTileBlocks - 1) / kHistTileBlocks;
+    long long grid = (tilesPerImage + 3) / 4;
+    // Five workgroups per CU: measured best for the 16384 x 16384 image (1024: 199 us, 1280: 191, 2048: 195).
+    const long long cap = g.batch > 1 ? (4096 / g.batch > 8 ? 4096 / g.batch : 8) : 1280;
+    if (grid > cap) grid = cap;
+    HistogramExport none = {nullptr, 0, nullptr};
+    if (ex != nullptr) ex->expected += (unsigned long long)grid;
+    hipLaunchKernelGGL(k_histogram_tiles<4>, dim3((unsigned)grid, (unsigned)g.batch), dim3(256), 0, s, g, d_coef, d_hist,
+                       ex != nullptr ? *ex : none);
+    return hipGetLastError();
+}
 
 static long long group_tiles_per_image(long long blocksPerImage, int tileBlocks) {
     return ((blocksPerImage + tileBlocks - 1) / tileBlocks + 3) / 4 * 4;

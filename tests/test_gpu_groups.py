@@ -19,11 +19,13 @@ pytestmark = pytest.mark.gpu
 def ctx():
     os.environ["JPEGENC_GROUP_MIN_BLOCKS"] = "0"
     os.environ["JPEGENC_SLOTS_MIN_BLOCKS"] = "0"      # tiles of 256 blocks leave their bits in slots (deferred placement)
+    os.environ["JPEGENC_HIST_TILES_MIN_BLOCKS"] = "0"  # the histogram pass on groups as well (k_histogram_tiles)
     c = B.Context(0)
     yield c
     c.close()
     os.environ.pop("JPEGENC_GROUP_MIN_BLOCKS", None)
     os.environ.pop("JPEGENC_SLOTS_MIN_BLOCKS", None)
+    os.environ.pop("JPEGENC_HIST_TILES_MIN_BLOCKS", None)
     os.environ.pop("JPEGENC_GROUP_TILE", None)
 
 
@@ -45,6 +47,22 @@ def test_files_bit_exact(ctx, scheme, tile):
         enc = O.encode(img, T.SCHEMES[scheme], qt)
         prm = B.make_params(w, h, T.SCHEMES[scheme], qt)
         assert ctx.encode_host(img, prm) == enc.jpeg, (scheme, tile, w, h, kind, tname)
+
+
+@pytest.mark.parametrize("scheme", ["444", "420", "422", "411"])
+def test_histograms_counted_on_groups(ctx, scheme):
+    # the staged call: k_histogram_tiles' counts against the oracle's, restart intervals of every kind,
+    # sizes that end in partial tiles and MCUs, content with zero runs beyond sixteen and without
+    for (w, h, kind, tname, ri) in [(640, 360, "natural", "annexk", 0), (333, 77, "noise", "annexk", 1), (250, 130, "noise", "ones", 7),
+                                    (1, 1, "natural", "ps12", 0), (1030, 9, "natural", "ps5", 3), (9, 500, "noise", "annexk", 40)]:
+        img = synth.generate(kind, w, h, seed=w * 3 + h)
+        qt = T.NAMED_TABLES[tname]
+        enc = O.encode(img, T.SCHEMES[scheme], qt, restart_interval=ri)
+        prm = B.make_params(w, h, T.SCHEMES[scheme], qt, restart_interval=ri)
+        ctx.begin(prm)
+        ctx.upload_pixels(img)
+        ctx.transform()
+        assert np.array_equal(ctx.histograms(), enc.hist), (scheme, w, h, kind, tname, ri)
 
 
 @pytest.mark.parametrize("tile", [256, 16])
