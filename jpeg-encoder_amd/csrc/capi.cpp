@@ -1241,14 +1241,19 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
         halfBits[0] = -1;
         set_halves(0);
     } else {
-    // The histogram pass runs in up to eight parts, each followed (on a stream of its own, so
+    // The histogram pass runs in up to four parts, each followed (on a stream of its own, so
     // that the parts stay back to back) by the copy of its histograms: the host builds the
     // tables of one part, and sends them back on a third stream, while the device works on
     // the next ones.  Sixteen host threads need about as long for the tables of a pass as
     // the device for its histograms.
     if (!ctx->histStream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->histStream, hipStreamNonBlocking));
     if (!ctx->tableStream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->tableStream, hipStreamNonBlocking));
-    parts = n / 16 < 1 ? 1 : (n / 16 > kBatchParts ? kBatchParts : n / 16);
+    // Four parts measure best for 256 frames of 1080p (1.72 ms per pass; two parts 1.78, eight 1.77: a part is a
+    // launch of its own, and the fewer there are the later the host starts).  Diagnostic switch
+    // JPEGENC_BATCH_PARTS: another upper limit.
+    static const int partsLimit = getenv("JPEGENC_BATCH_PARTS") ? atoi(getenv("JPEGENC_BATCH_PARTS")) : 4;
+    const int maxParts = partsLimit < 1 ? 1 : (partsLimit > kBatchParts ? kBatchParts : partsLimit);
+    parts = n / 16 < 1 ? 1 : (n / 16 > maxParts ? maxParts : n / 16);
     // The transform runs in two launches: one would let the host start later, one per part
     // costs the transform a tenth of its speed.
     const int groups = parts >= 4 ? 2 : 1;

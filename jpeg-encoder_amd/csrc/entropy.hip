@@ -165,8 +165,11 @@ __device__ __forceinline__ void flush_histograms(u32* lh, u64* __restrict__ hist
     u64 seen = 0;
 #pragma unroll
     for (int k = 0; k < 1024 / kEntThreads; ++k) seen |= old[k];
-    // `seen` is there to be waited for, in front of the barrier: a store that depends on it
-    // (under a condition that never holds) cannot move behind.
+    // The returned values have to be here before the workgroup counts itself off: an explicit wait
+    // for the vector memory counter (the additions are in flight on it), and `seen`, on which a
+    // store depends (under a condition that never holds), so that the compiler cannot move the
+    // additions behind the barrier either.
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
     if (seen == ~0ull) lh[0] = 0;
     __syncthreads();
     if (threadIdx.x == 0) lastOne = atomicAdd(ex.counter, 1ull) + 1 == ex.expected;
@@ -240,7 +243,10 @@ hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, 
     // Large images: one lane per group of eight coefficients that is not empty (k_histogram_tiles).
     // (Diagnostic switch JPEGENC_HIST_FORM=1: always one lane per block.)
     static const bool perBlock = getenv("JPEGENC_HIST_FORM") != nullptr && getenv("JPEGENC_HIST_FORM")[0] == '1';
-    if (!perBlock && g.groupMask != nullptr && g.blocksPerImage >= histogram_tiles_min_blocks()) {
+    // A batch counts by its whole size, as long as an image has tiles for every wave of a few workgroups
+    // (64 x 1080p 4:2:0, 3.1 million blocks: 111 against 120 us).
+    const long long counted = g.batch > 1 && g.blocksPerImage >= 16384 ? g.blocksPerImage * g.batch : g.blocksPerImage;
+    if (!perBlock && g.groupMask != nullptr && counted >= histogram_tiles_min_blocks()) {
         const hipError_t e = launch_histogram_tiles(g, d_coef, d_hist, s, ex != nullptr && g.batch == 1 ? ex : nullptr);
         return e;
     }

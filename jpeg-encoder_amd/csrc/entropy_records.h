@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void k_symbol_records(KGeom g, const int16_t* 
     u64 seen = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) seen |= old[k];
-    if (seen == ~0ull) lh[0] = 0;   // waits for the additions in front of the barrier (see k_histogram)
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the additions have returned (see flush_histograms)
+    if (seen == ~0ull) lh[0] = 0;
     __syncthreads();
     if (threadIdx.x == 0) lastOne = atomicAdd(ex.counter, 1ull) + 1 == ex.expected;
     __syncthreads();
