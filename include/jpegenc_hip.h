@@ -58,7 +58,8 @@ enum {
  * sampling: SamplingDefinition (SamplingScheme.h:25-44) -- per channel Y, Cb, Cr the four
  *   ChannelReductionOptions fields {widthFactor, widthMethod, heightFactor, heightMethod}.
  * qtable:   QTableSet (QuantizationTables.h:11-27) -- three tables of 64 floats in natural
- *   (row-major) order.
+ *   (row-major) order, each in [1, 256): DQT stores (byte)q (JPEGSegments.h:152-167).  Integer
+ *   divisors take the fast kernels; any other value is divided by as it is, in a slower kernel.
  * restart_interval: MCUs per restart interval; 0 reproduces the reference (one scan, no
  *   DRI/RSTn).  No counterpart in the reference.
  * pad_ones: 0 pads the last byte of the scan (and of every restart interval) with zero

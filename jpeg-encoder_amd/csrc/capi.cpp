@@ -25,6 +25,7 @@ static int gcd_i(int a, int b) { return b == 0 ? a : gcd_i(b, a % b); }
 static int lcm_i(int a, int b) { return a / gcd_i(a, b) * b; }
 
 int make_geometry(const jpeg_hip_params& p, Geometry& g) {
+    g.integerDivisors = true;
     if (p.width < 1 || p.height < 1 || p.width > 65535 || p.height > 65535) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     for (int c = 0; c < 3; ++c) {
         g.wf[c] = p.sampling[4 * c];
@@ -35,9 +36,13 @@ int make_geometry(const jpeg_hip_params& p, Geometry& g) {
         if ((g.wm[c] != JPEG_HIP_SUBSAMPLING && g.wm[c] != JPEG_HIP_AVERAGE) ||
             (g.hm[c] != JPEG_HIP_SUBSAMPLING && g.hm[c] != JPEG_HIP_AVERAGE))
             return JPEG_HIP_ERR_INVALID_ARGUMENT;
+        // QTable takes any float (QuantizationTables.h:6-27) and the DQT segment stores (byte)q
+        // (JPEGSegments.h:152-167), so a divisor has to lie in [1, 256).  Integers take the fast
+        // kernels, anything else the kernel that really divides.
         for (int i = 0; i < 64; ++i) {
             const float q = p.qtable[c][i];
-            if (!(q >= 1.0f && q <= 255.0f) || q != std::floor(q)) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+            if (!(q >= 1.0f && q < 256.0f)) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+            if (q != std::floor(q)) g.integerDivisors = false;
         }
     }
     if (p.restart_interval < 0 || p.restart_interval > 65535) return JPEG_HIP_ERR_INVALID_ARGUMENT;
@@ -147,6 +152,7 @@ void fill_kgeom(jpeg_hip_ctx* ctx) {
     k.strideBytes = ctx->stride;
     k.sampleFormat = ctx->fmt;
     k.stages = JPEG_HIP_STAGE_ALL;
+    k.trueDivision = g.integerDivisors ? 0 : 1;
     k.mcusPerRow = g.mcusPerRow;
     k.nMcu = g.nMcu;
     k.totalBlocks = g.totalBlocks;

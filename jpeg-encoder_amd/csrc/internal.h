@@ -28,6 +28,7 @@ struct Geometry {
     int64_t intervals;          // restart intervals in the band
     int64_t firstInterval;      // index of the band's first interval in the whole image
     bool startsImage, endsImage;
+    bool integerDivisors;       // every quantization divisor is an integer 1..255: the reciprocal form of the division is exact
 };
 
 // Fills `g`; returns a JPEG_HIP_* status.

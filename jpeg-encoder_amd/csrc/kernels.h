@@ -15,6 +15,7 @@ struct KGeom {
     long long strideBytes;   // RGB row stride
     int sampleFormat;        // JPEG_HIP_RGB8 / JPEG_HIP_RGBF32
     int stages;              // JPEG_HIP_STAGE_* bits
+    int trueDivision;        // a quantization divisor is not an integer 1..255: only the generic kernel (IEEE division) is exact
     int mcusPerRow;
     long long nMcu;          // MCUs in the band
     long long totalBlocks;

@@ -1115,6 +1115,12 @@ static bool scheme_is(const KGeom& g, int wf, int hf, int method) {
 
 hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef,
                             unsigned char* d_gmask, hipStream_t s, unsigned long long* d_clearHist) {
+    if (g.trueDivision) {   // the other kernels divide by multiplying with a two-term reciprocal, exact for integer divisors only
+        const long long grid = (g.totalBlocks + kGenThreads - 1) / kGenThreads;
+        hipLaunchKernelGGL(k_transform_generic, dim3((unsigned)grid), dim3(kGenThreads), 0, s, g, d_rgb, d_qtab, d_coef,
+                           d_gmask, d_clearHist);
+        return hipGetLastError();
+    }
     const bool bytesAligned = g.sampleFormat == JPEG_HIP_RGB8 && g.stages == JPEG_HIP_STAGE_ALL && g.nGains == 0 &&
                               (g.strideBytes & 3) == 0 && ((uintptr_t)d_rgb & 3) == 0 &&
                               (g.batch == 1 || (g.imageStrideBytes & 3) == 0);

@@ -68,6 +68,32 @@ def test_random_configurations_byte_identical(ctx, seed):
         assert got == want, (seed, w, h, ri, pad, which)
 
 
+def test_divisors_that_are_not_integers(ctx):
+    # QTable takes any float (QuantizationTables.h:6-27): the transform then has to divide for
+    # real (the reciprocal form is exact for integers only), and DQT stores (byte)q
+    # (JPEGSegments.h:152-167).  Byte and float pixels, every scheme family, ragged sizes.
+    rng = np.random.RandomState(77)
+    for k, (w, h, name) in enumerate([(97, 61, "420"), (64, 48, "444"), (333, 40, "422"), (50, 130, "411"), (1, 1, "420")]):
+        scheme = T.SCHEMES[name]
+        qt = (1.0 + rng.rand(3, 64) * 254.9).astype(np.float32)
+        if k == 1:
+            qt = (T.STANDARD_TABLES * np.float32(0.37) + np.float32(1.0)).astype(np.float32)
+        img = _content(rng, w, h)
+        want = O.encode(img, scheme, qt).jpeg
+        assert ctx.encode_host(img, B.make_params(w, h, scheme, qt)) == want, (w, h, name)
+        imgf = (img.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+        wantf = O.encode(imgf, scheme, qt).jpeg
+        assert ctx.encode_host(imgf, B.make_params(w, h, scheme, qt)) == wantf, (w, h, name, "float")
+    # out of range stays an error
+    bad = T.STANDARD_TABLES.copy()
+    bad[0, 5] = 256.0
+    with pytest.raises(B.JpegHipError):
+        ctx.begin(B.make_params(16, 16, T.SCHEME_444, bad))
+    bad[0, 5] = 0.5
+    with pytest.raises(B.JpegHipError):
+        ctx.begin(B.make_params(16, 16, T.SCHEME_444, bad))
+
+
 def test_mostly_flat_image_with_long_blocks(ctx):
     # Mean block length far below 128 bits (the short-block bit writer is chosen), but a
     # band of noise at q=100 whose blocks overflow the private words and take the second walk.
