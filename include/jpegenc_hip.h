@@ -226,6 +226,14 @@ int jpeg_hip_histograms_host(jpeg_hip_ctx* ctx, uint64_t* h_hist);
  * lengths[s] == 0 marks an unused symbol; codes are right aligned. */
 int jpeg_hip_huffman_from_histogram(const uint64_t counts[256], uint8_t lengths[256], uint16_t codes[256]);
 
+/* HuffmanTable<byte>::create(codeWordLength, symbols) (HuffmanCodingByte.h:102-210) for any limit
+ * the reference accepts: 9 (its lower bound ceil(log2(256 + 1)), :121) to 64 (the width of its
+ * code word, :105); anything else is JPEG_HIP_ERR_INVALID_ARGUMENT where the reference returns a
+ * null table.  Codes are right aligned in 64 bits.  Pure host function; only tables of at most
+ * 16 bits can go on to jpeg_hip_set_huffman / jpeg_hip_write_dht. */
+int jpeg_hip_huffman_from_histogram_limit(const uint64_t counts[256], int code_word_length, uint8_t lengths[256],
+                                          uint64_t codes[256]);
+
 /* The typical Huffman tables of ITU-T T.81 Annex K.3 in the layout of jpeg_hip_get_huffman:
  * [0] DC luminance (table K.3), [1] DC chrominance (K.4), [2] AC luminance (K.5), [3] AC
  * chrominance (K.6), with the canonical codes of Annex C.  No counterpart in the reference

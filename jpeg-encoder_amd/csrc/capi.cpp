@@ -875,6 +875,15 @@ int jpeg_hip_huffman_from_histogram(const uint64_t counts[256], uint8_t lengths[
     return JPEG_HIP_OK;
 }
 
+int jpeg_hip_huffman_from_histogram_limit(const uint64_t counts[256], int code_word_length, uint8_t lengths[256],
+                                          uint64_t codes[256]) {
+    if (!counts || !lengths || !codes) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    // HuffmanCodingByte.h:105 (no longer than the 64-bit code word) and :121 (ceil(log2(256 + 1)) = 9 at least).
+    if (code_word_length < 9 || code_word_length > 64) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    huffman_from_histogram_limit(counts, code_word_length, lengths, codes);
+    return JPEG_HIP_OK;
+}
+
 int jpeg_hip_standard_huffman(uint8_t lengths[4][256], uint16_t codes[4][256]) {
     if (!lengths || !codes) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     standard_huffman(lengths, codes);

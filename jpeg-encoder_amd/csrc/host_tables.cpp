@@ -26,8 +26,14 @@ const int kZigZagOrder[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18
 const int* zigzag_order() { return kZigZagOrder; }
 
 void huffman_from_histogram(const uint64_t counts[256], uint8_t lengths[256], uint16_t codes[256]) {
+    uint64_t wide[256];
+    huffman_from_histogram_limit(counts, 16, lengths, wide);
+    for (int s = 0; s < 256; ++s) codes[s] = (uint16_t)wide[s];
+}
+
+void huffman_from_histogram_limit(const uint64_t counts[256], int maxLen, uint8_t lengths[256], uint64_t codes[256]) {
     memset(lengths, 0, 256);
-    memset(codes, 0, 512);
+    memset(codes, 0, 256 * sizeof(uint64_t));
 
     // Leaves in ascending symbol order, then the zero-frequency dummy that keeps the
     // all-ones code unused (HuffmanCodingByte.h:124-135).
@@ -39,7 +45,7 @@ void huffman_from_histogram(const uint64_t counts[256], uint8_t lengths[256], ui
     const int dummy = nLeaves;
     leafSymbol[nLeaves++] = 0;
 
-    const int kMaxLen = 16;
+    const int kMaxLen = maxLen;
     // Pool: leaves first, then every package in creation order, so a package's children
     // always sit at lower indices than the package itself.
     std::vector<uint64_t> freq;
@@ -93,7 +99,7 @@ void huffman_from_histogram(const uint64_t counts[256], uint8_t lengths[256], ui
         if (len != lastLen) code >>= (lastLen - len);
         --code;
         lengths[leafSymbol[leaf]] = (uint8_t)len;
-        codes[leafSymbol[leaf]] = (uint16_t)code;
+        codes[leafSymbol[leaf]] = code;
         lastLen = len;
     }
 }

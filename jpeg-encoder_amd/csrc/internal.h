@@ -38,6 +38,8 @@ const int* zigzag_order();
 // ITU-T T.81 Annex K.3 typical tables (K.3-K.6) as [DC-Y, DC-C, AC-Y, AC-C], canonical codes (Annex C).
 void standard_huffman(uint8_t lengths[4][256], uint16_t codes[4][256]);
 void huffman_from_histogram(const uint64_t counts[256], uint8_t lengths[256], uint16_t codes[256]);
+// The same for any limit on the code length (HuffmanTable<byte>::create's first argument, 9..64).
+void huffman_from_histogram_limit(const uint64_t counts[256], int maxLen, uint8_t lengths[256], uint64_t codes[256]);
 bool huffman_table_is_sane(const uint8_t lengths[256], const uint16_t codes[256]);
 int write_dht(const uint8_t lengths[256], const uint16_t codes[256], int tableId, int coefType, uint8_t* out,
               int capacity);

@@ -34,6 +34,26 @@ int main() {
     for (byte b : dec) std::cout << " " << (int)b;
     std::cout << "\nsymbols: " << table->getSymbolCount() << "\n";
 
+    // Other limits on the code length (HuffmanCodingByte.h:105, :121): a table of at most 9 bits
+    // for a skewed source, round trip through it; limits the reference refuses give no table.
+    {
+        std::vector<byte> skew;
+        for (int s = 0; s < 40; ++s)
+            for (int k = 0; k < (1 << (s < 20 ? 20 - s : 0)) && k < 4096; ++k) skew.push_back((byte)s);
+        auto t9 = HuffmanTable<byte>::create(9, skew);
+        size_t longest = 0;
+        for (const auto& p : *t9) longest = p.code->getSize() > longest ? p.code->getSize() : longest;
+        std::vector<byte> msg{0, 39, 7, 20, 1};
+        auto dec9 = t9->decode(t9->encode(msg));
+        std::cout << "limit9: longest " << longest << " symbols " << t9->getSymbolCount() << " roundtrip "
+                  << (dec9 == msg ? "ok" : "FAILED") << "\n";
+        auto t40 = HuffmanTable<byte>::create(40, skew);
+        auto dec40 = t40->decode(t40->encode(msg));
+        std::cout << "limit40: roundtrip " << (dec40 == msg ? "ok" : "FAILED") << "\n";
+        std::cout << "limit8: " << (HuffmanTable<byte>::create(8, skew) ? "table" : "null") << "\n";
+        std::cout << "limit65: " << (HuffmanTable<byte>::create(65, skew) ? "table" : "null") << "\n";
+    }
+
     // BitBuffer: escaped pushes, zero padding, unaligned getBits
     BitBuffer bb;
     const byte ones[2] = {0xff, 0xff};

@@ -174,14 +174,37 @@ HuffmanTablePtr<byte> HuffmanTable<byte>::fromLengthsAndCodes(const uint8_t len[
 }
 
 HuffmanTablePtr<byte> HuffmanTable<byte>::create(size_t codeWordLength, const std::vector<byte>& srcData) {
-    if (codeWordLength != 16) return nullptr;   // only the JPEG limit goes through the C ABI
+    if (codeWordLength > 64) return nullptr;   // HuffmanCodingByte.h:105
     if (srcData.empty()) return std::make_shared<HuffmanTable<byte>>(codeWordLength);
     uint64_t counts[256] = {0};
     for (byte s : srcData) counts[s]++;
     uint8_t len[256];
-    uint16_t cod[256];
-    if (jpeg_hip_huffman_from_histogram(counts, len, cod) != JPEG_HIP_OK) return nullptr;
-    return fromLengthsAndCodes(len, cod);
+    if (codeWordLength == 16) {   // the JPEG limit: the table the encoder and the DHT writer take
+        uint16_t cod[256];
+        if (jpeg_hip_huffman_from_histogram(counts, len, cod) != JPEG_HIP_OK) return nullptr;
+        return fromLengthsAndCodes(len, cod);
+    }
+    // Any other limit the reference accepts (below 9 it returns a null table, :121).
+    uint64_t wide[256];
+    if (jpeg_hip_huffman_from_histogram_limit(counts, (int)codeWordLength, len, wide) != JPEG_HIP_OK) return nullptr;
+    auto t = std::make_shared<HuffmanTable<byte>>(codeWordLength);
+    bool jpegSized = true;
+    for (int s = 0; s < 256; ++s) {
+        if (len[s] == 0) continue;
+        t->codedSymbolCount++;
+        auto code = std::make_shared<BitBuffer>();
+        const uint64_t aligned = wide[s] << (64 - len[s]);
+        byte be[8];
+        for (int k = 0; k < 8; ++k) be[k] = (byte)(aligned >> (56 - 8 * k));
+        code->pushBits(len[s], be);
+        t->codeMap[s] = SymbolCodePair((byte)s, code);
+        if (len[s] > 16) jpegSized = false;
+    }
+    if (jpegSized) {   // usable wherever a 16-bit table is
+        memcpy(t->lengths, len, 256);
+        for (int s = 0; s < 256; ++s) t->codes[s] = (uint16_t)wide[s];
+    }
+    return t;
 }
 
 BitBufferPtr HuffmanTable<byte>::encode(const std::vector<byte>& srcData) {
@@ -193,13 +216,22 @@ ConstBitBufferPtr HuffmanTable<byte>::encode(const byte& srcData) const { return
 
 std::vector<byte> HuffmanTable<byte>::decode(BitBufferPtr in) {
     std::vector<byte> out;
-    uint32_t cur = 0;
-    int n = 0;
+    // Lengths and code bits from the code words themselves (a table made for another limit than
+    // 16 may hold codes of up to 64 bits).
+    size_t lens[256] = {0};
+    uint64_t vals[256] = {0};
+    for (int s = 0; s < 256; ++s) {
+        if (!codeMap[s].code) continue;
+        lens[s] = codeMap[s].code->getSize();
+        for (size_t k = 0; k < lens[s]; ++k) vals[s] = (vals[s] << 1) | (codeMap[s].code->getBit(k) ? 1u : 0u);
+    }
+    uint64_t cur = 0;
+    size_t n = 0;
     for (size_t i = 0; i < in->getSize(); ++i) {
         cur = (cur << 1) | (in->getBit(i) ? 1u : 0u);
         ++n;
         for (int s = 0; s < 256; ++s)
-            if (lengths[s] == n && codes[s] == cur) {
+            if (lens[s] == n && vals[s] == cur) {
                 out.push_back((byte)s);
                 cur = 0;
                 n = 0;

@@ -22,7 +22,7 @@ EXPORTS = [
     "jpeg_hip_create", "jpeg_hip_destroy", "jpeg_hip_last_error", "jpeg_hip_status_string", "jpeg_hip_stream",
     "jpeg_hip_compute_layout", "jpeg_hip_encode", "jpeg_hip_encode_static", "jpeg_hip_static_workspace_bytes", "jpeg_hip_encode_host", "jpeg_hip_encode_batch", "jpeg_hip_encode_batch_host", "jpeg_hip_begin", "jpeg_hip_upload_pixels", "jpeg_hip_upload_planes",
     "jpeg_hip_bind_pixels", "jpeg_hip_transform", "jpeg_hip_histograms", "jpeg_hip_histograms_host",
-    "jpeg_hip_huffman_from_histogram", "jpeg_hip_standard_huffman", "jpeg_hip_write_dht", "jpeg_hip_write_headers", "jpeg_hip_set_huffman",
+    "jpeg_hip_huffman_from_histogram", "jpeg_hip_huffman_from_histogram_limit", "jpeg_hip_standard_huffman", "jpeg_hip_write_dht", "jpeg_hip_write_headers", "jpeg_hip_set_huffman",
     "jpeg_hip_build_huffman", "jpeg_hip_get_huffman", "jpeg_hip_emit_scan", "jpeg_hip_emit_scan_host",
     "jpeg_hip_get_coefficients",
     "jpeg_hip_coefficients_device", "jpeg_hip_encode_sharded", "jpeg_hip_allreduce_histograms", "jpeg_hip_comm_unique_id", "jpeg_hip_comm_create", "jpeg_hip_comm_destroy", "jpeg_hip_analyze_band", "jpeg_hip_finish_band", "jpeg_hip_finish_band_start", "jpeg_hip_finish_band_wait", "jpeg_hip_set_profiling",
@@ -107,6 +107,7 @@ def lib():
         L.jpeg_hip_histograms.argtypes = [vp, vp]
         L.jpeg_hip_histograms_host.argtypes = [vp, vp]
         L.jpeg_hip_huffman_from_histogram.argtypes = [vp, vp, vp]
+        L.jpeg_hip_huffman_from_histogram_limit.argtypes = [vp, i32, vp, vp]
         L.jpeg_hip_standard_huffman.argtypes = [vp, vp]
         L.jpeg_hip_write_dht.argtypes = [vp, vp, i32, i32, vp, i32]
         L.jpeg_hip_write_headers.argtypes = [C.POINTER(Params), vp, vp, vp, i32]
@@ -197,6 +198,17 @@ def huffman_from_histogram(counts):
     st = lib().jpeg_hip_huffman_from_histogram(_np(cnt), _np(lengths), _np(codes))
     if st != OK:
         raise JpegHipError(st, "huffman_from_histogram")
+    return lengths, codes
+
+
+def huffman_from_histogram_limit(counts, code_word_length):
+    """Pure host: (lengths u8[256], codes u64[256]) with no code longer than code_word_length (9..64)."""
+    cnt = np.ascontiguousarray(counts, np.uint64).reshape(256)
+    lengths = np.zeros(256, np.uint8)
+    codes = np.zeros(256, np.uint64)
+    st = lib().jpeg_hip_huffman_from_histogram_limit(_np(cnt), int(code_word_length), _np(lengths), _np(codes))
+    if st != OK:
+        raise JpegHipError(st, "huffman_from_histogram_limit")
     return lengths, codes
 
 

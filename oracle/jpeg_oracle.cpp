@@ -266,9 +266,10 @@ struct PmNode {
 struct HuffTable {
     u8 len[256];
     uint16_t code[256];       // right-aligned code bits
+    uint64_t wide[256];       // the same in full (limits above 16 bits)
     bool present[256];
     int symbolCount;
-    HuffTable() : symbolCount(0) { memset(len, 0, sizeof len); memset(code, 0, sizeof code); memset(present, 0, sizeof present); }
+    HuffTable() : symbolCount(0) { memset(len, 0, sizeof len); memset(code, 0, sizeof code); memset(wide, 0, sizeof wide); memset(present, 0, sizeof present); }
 };
 
 void incLeafLengths(const std::vector<PmNode>& pool, int idx, std::vector<uint32_t>& leafLen) {
@@ -332,6 +333,7 @@ bool buildHuffman(const uint64_t counts[256], HuffTable& out, size_t maxLen = 16
         int sym = leafSymbol[leaf];
         out.len[sym] = (u8)curLen;
         out.code[sym] = (uint16_t)code;
+        out.wide[sym] = code;
         out.present[sym] = true;
         lastLen = curLen;
     }
@@ -752,6 +754,18 @@ int orc_huffman(const uint64_t counts[256], int htNum, int htType, uint8_t lengt
     if ((int)seg.size() > dhtCap) return -1;
     if (!seg.empty()) memcpy(dht, seg.data(), seg.size());
     return (int)seg.size();
+}
+
+// HuffmanTable<byte>::create(codeWordLength, symbols) for any limit; -1 where the reference
+// returns a null table (HuffmanCodingByte.h:105, :121).
+int orc_huffman_limit(const uint64_t counts[256], int codeWordLength, uint8_t lengths[256], uint64_t codes[256]) {
+    if (codeWordLength > 64) return -1;
+    if ((double)codeWordLength < std::ceil(std::log2(256.0 + 1.0))) return -1;
+    HuffTable t;
+    buildHuffman(counts, t, (size_t)codeWordLength);
+    memcpy(lengths, t.len, 256);
+    memcpy(codes, t.wide, sizeof t.wide);
+    return 0;
 }
 
 // BitBuffer::pushBits[Escaped] replay: n pushes of (nbits[i], 4 source bytes each,

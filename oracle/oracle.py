@@ -124,6 +124,19 @@ def huffman(counts, ht_num=0, ht_type=0):
     return lengths, codes, dht[:n].tobytes()
 
 
+def huffman_limit(counts, code_word_length):
+    """-> (lengths[256] u8, codes[256] u64), or None where the reference returns a null table."""
+    cnt = np.ascontiguousarray(counts, np.uint64).reshape(256)
+    lengths = np.zeros(256, np.uint8)
+    codes = np.zeros(256, np.uint64)
+    L = lib()
+    L.orc_huffman_limit.restype = C.c_int
+    L.orc_huffman_limit.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    if L.orc_huffman_limit(_p(cnt), int(code_word_length), _p(lengths), _p(codes)) != 0:
+        return None
+    return lengths, codes
+
+
 def bitbuffer_replay(pushes, escape=True, fill=True):
     """pushes: list of (nbits, value) with value right-aligned; -> (bytes, bit length)."""
     n = len(pushes)

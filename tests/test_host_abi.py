@@ -57,6 +57,29 @@ def test_huffman_tables_match_oracle(kind):
         assert abs(kraft - 1.0) < 1e-12 or kind == "few"
 
 
+@pytest.mark.parametrize("limit", [9, 10, 12, 16, 20, 33, 64])
+def test_huffman_tables_of_other_code_word_lengths_match_oracle(limit):
+    # HuffmanTable<byte>::create(codeWordLength, ...) for the limits the reference accepts (9..64).
+    rng = np.random.RandomState(limit)
+    for kind in ("few", "ties", "geometric", "dense"):
+        for _ in range(8):
+            h = _random_hist(rng, kind)
+            lo, co = O.huffman_limit(h, limit)
+            lp, cp = B.huffman_from_histogram_limit(h, limit)
+            assert np.array_equal(lo, lp) and np.array_equal(co, cp), (limit, kind)
+            assert lp.max() <= limit
+            if limit == 16:
+                l16, c16 = B.huffman_from_histogram(h)
+                assert np.array_equal(l16, lp) and np.array_equal(c16.astype(np.uint64), cp)
+            # a prefix code that leaves the all-ones word free: Kraft sum below one
+            used = [int(l) for l in lp if l]
+            assert sum(2.0 ** -l for l in used) <= 1.0 - 2.0 ** -max(used) + 1e-12
+    for bad in (0, 8, 65):
+        assert O.huffman_limit(np.ones(256), bad) is None
+        with pytest.raises(B.JpegHipError):
+            B.huffman_from_histogram_limit(np.ones(256), bad)
+
+
 def test_huffman_reference_kat_through_abi():
     cnt = np.bincount([0, 1] + [2] * 3 + [3] * 5 + [4] * 6 + [5] * 11 + [6] * 13, minlength=256)
     lengths, codes = B.huffman_from_histogram(cnt)

@@ -29,6 +29,13 @@ def test_huffman_table_class_reproduces_reference_kat():
     assert r["symbols"] == "7"
 
 
+def test_huffman_table_class_takes_other_code_word_lengths():
+    r = _selftest()
+    assert r["limit9"] == "longest 9 symbols 40 roundtrip ok"
+    assert r["limit40"] == "roundtrip ok"
+    assert r["limit8"] == "null" and r["limit65"] == "null"   # HuffmanCodingByte.h:121 and :105
+
+
 def test_bitbuffer_escaping_and_padding():
     r = _selftest()
     # 16 one-bits escaped (two stuffed zeros), then 9 plain bits 1010 0101 1, zero padded
