@@ -20,7 +20,14 @@ static std::string hex(const BitBuffer& b) {
     return s;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    // host_selftest convert <image in> <image out>: ImageLoader::Load + Save on the host alone.
+    if (argc == 4 && std::string(argv[1]) == "convert") {
+        ImagePtr image = ImageLoader::Load(argv[2], Sampling::Scheme444);
+        if (!image) return 1;
+        ImageLoader::Save(argv[3], image);
+        return 0;
+    }
     // testHuffmanEncoding
     std::vector<byte> all{0, 1, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5,
                           6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6};

@@ -592,8 +592,83 @@ void ImageLoader::SavePPM(std::string path, ImagePtr image) {
     }
 }
 
-// Minimal PNG codec on zlib: 8-bit grey / RGB / palette / grey+alpha / RGBA, no interlace.
+// PNG reader on zlib: every colour type and bit depth of the format (grey 1/2/4/8/16, RGB 8/16,
+// palette 1/2/4/8, grey+alpha and RGBA 8/16), plain or Adam7 interlaced.  Samples come out as the
+// 8-bit RGB that lodepng::decode hands the reference (ImageLoader.cpp:180-193): the high byte of a
+// 16-bit sample, value * 255 / (2^depth - 1) for a grey sample of fewer than 8 bits, alpha dropped.
 static uint32_t be32(const byte* p) { return ((uint32_t)p[0] << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
+
+namespace {
+
+struct PngFormat {
+    int depth, colour, channels;
+    const std::vector<byte>* palette;
+    size_t lineBytes(uint32_t w) const { return ((size_t)w * channels * depth + 7) / 8; }
+    size_t filterUnit() const { return (size_t)std::max(1, channels * depth / 8); }
+};
+
+// Undoes the line filters of one (sub-)image of w x h pixels at `raw` in place and writes its
+// pixels to rgb at (x0 + x * dx, y0 + y * dy) of an image `width` pixels wide.  Returns the bytes used.
+size_t pngPass(const PngFormat& f, byte* raw, uint32_t w, uint32_t h, byte* rgb, uint32_t width, uint32_t x0, uint32_t y0,
+               uint32_t dx, uint32_t dy) {
+    if (w == 0 || h == 0) return 0;
+    const size_t stride = f.lineBytes(w), bpp = f.filterUnit();
+    std::vector<byte> zero(stride, 0);
+    for (uint32_t y = 0; y < h; ++y) {
+        byte* cur = &raw[(stride + 1) * y + 1];
+        const byte* prev = y > 0 ? &raw[(stride + 1) * (y - 1) + 1] : zero.data();
+        switch (cur[-1]) {
+        case 1:
+            for (size_t i = bpp; i < stride; ++i) cur[i] = (byte)(cur[i] + cur[i - bpp]);
+            break;
+        case 2:
+            for (size_t i = 0; i < stride; ++i) cur[i] = (byte)(cur[i] + prev[i]);
+            break;
+        case 3:
+            for (size_t i = 0; i < bpp && i < stride; ++i) cur[i] = (byte)(cur[i] + (prev[i] >> 1));
+            for (size_t i = bpp; i < stride; ++i) cur[i] = (byte)(cur[i] + ((cur[i - bpp] + prev[i]) >> 1));
+            break;
+        case 4:
+            for (size_t i = 0; i < bpp && i < stride; ++i) cur[i] = (byte)(cur[i] + prev[i]);   // a = c = 0: the predictor is b
+            for (size_t i = bpp; i < stride; ++i) {
+                const int a = cur[i - bpp], b = prev[i], c = prev[i - bpp];
+                const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+                cur[i] = (byte)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)));
+            }
+            break;
+        default:
+            break;
+        }
+        byte* line = &rgb[((size_t)(y0 + y * dy) * width + x0) * 3];
+        if (f.colour == 2 && f.depth == 8 && dx == 1) {
+            memcpy(line, cur, (size_t)w * 3);
+            continue;
+        }
+        for (uint32_t x = 0; x < w; ++x) {
+            byte* o = line + (size_t)x * dx * 3;
+            unsigned v[4] = {0, 0, 0, 0};   // the pixel's samples, 8 bits each (or the palette index)
+            if (f.depth >= 8) {
+                const byte* src = &cur[(size_t)x * f.channels * (f.depth / 8)];
+                for (int k = 0; k < f.channels; ++k) v[k] = src[(size_t)k * (f.depth / 8)];   // 16 bits: the high byte
+            } else {
+                const size_t bit = (size_t)x * f.depth;
+                const unsigned raw1 = (cur[bit >> 3] >> (8 - f.depth - (bit & 7))) & ((1u << f.depth) - 1u);
+                v[0] = f.colour == 3 ? raw1 : raw1 * 255u / ((1u << f.depth) - 1u);
+            }
+            if (f.colour == 3) {
+                const size_t pi = (size_t)v[0] * 3;
+                for (int k = 0; k < 3; ++k) o[k] = pi + k < f.palette->size() ? (*f.palette)[pi + k] : 0;
+            } else if (f.colour == 2 || f.colour == 6) {
+                o[0] = (byte)v[0]; o[1] = (byte)v[1]; o[2] = (byte)v[2];
+            } else {
+                o[0] = o[1] = o[2] = (byte)v[0];
+            }
+        }
+    }
+    return (stride + 1) * h;
+}
+
+}  // namespace
 
 ImagePtr ImageLoader::LoadPNG(std::string path, SamplingDefinition scheme) {
     std::ifstream in(path, std::ios::binary | std::ios::ate);
@@ -632,58 +707,42 @@ ImagePtr ImageLoader::LoadPNG(std::string path, SamplingDefinition scheme) {
         pos += 12 + len;
     }
     const int channels = colour == 0 ? 1 : colour == 2 ? 3 : colour == 3 ? 1 : colour == 4 ? 2 : colour == 6 ? 4 : 0;
-    if (width == 0 || height == 0 || depth != 8 || channels == 0 || interlace != 0) {
+    // Depths the format allows per colour type (PNG specification, table 11.1).
+    const bool depthOk = colour == 0   ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                         : colour == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8)
+                                       : (depth == 8 || depth == 16);
+    if (width == 0 || height == 0 || channels == 0 || !depthOk || interlace > 1) {
         std::cout << "Failed to decode png " << path << ": unsupported format" << std::endl;
         return nullptr;
     }
-    const size_t stride = (size_t)width * channels;
-    std::vector<byte> raw((stride + 1) * height);
+    const PngFormat fmt = {depth, colour, channels, &palette};
+    // Adam7: seven sub-images, each with its own lines and filter bytes (first pixel, step).
+    static const uint32_t px0[7] = {0, 4, 0, 2, 0, 1, 0}, py0[7] = {0, 0, 4, 0, 2, 0, 1};
+    static const uint32_t pdx[7] = {8, 8, 4, 4, 2, 2, 1}, pdy[7] = {8, 8, 8, 4, 4, 2, 2};
+    size_t total = 0;
+    if (interlace) {
+        for (int p = 0; p < 7; ++p) {
+            const uint32_t w = (width + pdx[p] - 1 - px0[p]) / pdx[p], h = (height + pdy[p] - 1 - py0[p]) / pdy[p];
+            if (w != 0 && h != 0) total += (fmt.lineBytes(w) + 1) * h;
+        }
+    } else {
+        total = (fmt.lineBytes(width) + 1) * height;
+    }
+    std::vector<byte> raw(total);
     uLongf rawLen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size()) {
         std::cout << "Failed to decode png " << path << ": inflate error" << std::endl;
         return nullptr;
     }
-    // Undo the line filters in place (one loop per filter type), then bring the samples to RGB.
-    std::vector<byte> zero(stride, 0), rgb((size_t)width * height * 3);
-    const size_t bpp = (size_t)channels;
-    for (uint32_t y = 0; y < height; ++y) {
-        byte* cur = &raw[(stride + 1) * y + 1];
-        const byte* prev = y > 0 ? &raw[(stride + 1) * (y - 1) + 1] : zero.data();
-        switch (cur[-1]) {
-        case 1:
-            for (size_t i = bpp; i < stride; ++i) cur[i] = (byte)(cur[i] + cur[i - bpp]);
-            break;
-        case 2:
-            for (size_t i = 0; i < stride; ++i) cur[i] = (byte)(cur[i] + prev[i]);
-            break;
-        case 3:
-            for (size_t i = 0; i < bpp; ++i) cur[i] = (byte)(cur[i] + (prev[i] >> 1));
-            for (size_t i = bpp; i < stride; ++i) cur[i] = (byte)(cur[i] + ((cur[i - bpp] + prev[i]) >> 1));
-            break;
-        case 4:
-            for (size_t i = 0; i < bpp; ++i) cur[i] = (byte)(cur[i] + prev[i]);   // a = c = 0: the predictor is b
-            for (size_t i = bpp; i < stride; ++i) {
-                const int a = cur[i - bpp], b = prev[i], c = prev[i - bpp];
-                const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
-                cur[i] = (byte)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)));
-            }
-            break;
-        default:
-            break;
+    std::vector<byte> rgb((size_t)width * height * 3);
+    if (interlace) {
+        size_t at = 0;
+        for (int p = 0; p < 7; ++p) {
+            const uint32_t w = (width + pdx[p] - 1 - px0[p]) / pdx[p], h = (height + pdy[p] - 1 - py0[p]) / pdy[p];
+            at += pngPass(fmt, raw.data() + at, w, h, rgb.data(), width, px0[p], py0[p], pdx[p], pdy[p]);
         }
-        byte* o = &rgb[(size_t)y * width * 3];
-        if (colour == 2) {
-            memcpy(o, cur, (size_t)width * 3);
-        } else {
-            for (uint32_t x = 0; x < width; ++x, o += 3) {
-                const byte* s = &cur[(size_t)x * channels];
-                if (colour == 6) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; }
-                else if (colour == 3) {
-                    const size_t pi = (size_t)s[0] * 3;
-                    for (int k = 0; k < 3; ++k) o[k] = pi + k < palette.size() ? palette[pi + k] : 0;
-                } else { o[0] = o[1] = o[2] = s[0]; }
-            }
-        }
+    } else {
+        pngPass(fmt, raw.data(), width, height, rgb.data(), width, 0, 0, 1, 1);
     }
     ImagePtr image = std::make_shared<Image>((size_t)width, (size_t)height, scheme);
     image->setRawPixelData8(rgb.data());

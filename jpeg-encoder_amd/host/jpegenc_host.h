@@ -313,7 +313,7 @@ public:
     static void Save(const std::string& filename, ImagePtr image);
     static void Save(const std::string& filename, EncoderPtr encoder);
     static ImagePtr LoadPPM(std::string path, SamplingDefinition scheme);  // ASCII P3 (and binary P6)
-    static ImagePtr LoadPNG(std::string path, SamplingDefinition scheme);  // 8-bit, non-interlaced PNG
+    static ImagePtr LoadPNG(std::string path, SamplingDefinition scheme);  // every colour type and bit depth, plain or interlaced
     static void SavePPM(std::string path, ImagePtr image);
     static void SavePNG(std::string path, ImagePtr image);
     static void SaveJPG(std::string path, EncoderPtr encoder);

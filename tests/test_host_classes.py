@@ -36,6 +36,104 @@ def test_huffman_table_class_takes_other_code_word_lengths():
     assert r["limit8"] == "null" and r["limit65"] == "null"   # HuffmanCodingByte.h:121 and :105
 
 
+def _png_bytes(samples, colour, depth, interlace, palette=None, filters=(0, 1, 2, 3, 4)):
+    """A PNG file from samples [H, W, channels] (integers of `depth` bits), written with the given
+    line filters in turn; Adam7 when `interlace`."""
+    import struct
+    import zlib
+
+    h, w, ch = samples.shape
+
+    def pack_line(row):          # row: [w, ch] -> bytes, samples MSB first
+        if depth == 16:
+            return row.astype(">u2").tobytes()
+        if depth == 8:
+            return row.astype(np.uint8).tobytes()
+        bits = "".join(format(int(v), "0%db" % depth) for v in row.reshape(-1))
+        bits += "0" * (-len(bits) % 8)
+        return bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+
+    bpp = max(1, ch * depth // 8)
+
+    def filtered(lines):
+        out, prev = bytearray(), None
+        for k, line in enumerate(lines):
+            ft = filters[k % len(filters)]
+            cur = bytearray(line)
+            up = prev if prev is not None else bytearray(len(cur))
+            res = bytearray(len(cur))
+            for i in range(len(cur)):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = up[i]
+                c = up[i - bpp] if i >= bpp else 0
+                if ft == 0:
+                    pred = 0
+                elif ft == 1:
+                    pred = a
+                elif ft == 2:
+                    pred = b
+                elif ft == 3:
+                    pred = (a + b) >> 1
+                else:
+                    p = a + b - c
+                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                res[i] = (cur[i] - pred) & 255
+            out.append(ft)
+            out += res
+            prev = cur
+        return bytes(out)
+
+    if interlace:
+        raw = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = samples[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += filtered([pack_line(r) for r in sub])
+    else:
+        raw = filtered([pack_line(r) for r in samples])
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xffffffff)
+
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, colour, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        out += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    half = len(raw) // 2       # two IDAT chunks: the stream may be split anywhere
+    z = zlib.compress(raw)
+    return out + chunk(b"IDAT", z[:len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("interlace", [False, True])
+def test_png_reader_takes_every_colour_type_and_depth(tmp_path, interlace):
+    # What lodepng::decode hands the reference (ImageLoader.cpp:180-193): RGBA8 -- the high byte of 16-bit
+    # samples, grey of fewer bits scaled by 255 / (2^depth - 1), palette looked up -- of which R, G, B are used.
+    from PIL import Image
+    rng = np.random.RandomState(3)
+    exe = os.path.join(LIB, "host_selftest")
+    cases = [(0, d) for d in (1, 2, 4, 8, 16)] + [(2, 8), (2, 16)] + [(3, d) for d in (1, 2, 4, 8)] + [(4, 8), (4, 16), (6, 8), (6, 16)]
+    for colour, depth in cases:
+        for (w, h) in ((1, 1), (5, 3), (13, 17), (37, 9)):
+            ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[colour]
+            samples = rng.randint(0, 1 << depth, (h, w, ch))
+            palette = rng.randint(0, 256, (1 << depth, 3)) if colour == 3 else None
+            if colour == 3:
+                want = palette[samples[..., 0]]
+            else:
+                s8 = samples >> 8 if depth == 16 else (samples * 255 // ((1 << depth) - 1) if depth < 8 else samples)
+                want = s8[..., :3] if ch >= 3 else np.repeat(s8[..., :1], 3, axis=2)
+            src, dst = tmp_path / "in.png", tmp_path / "out.ppm"
+            src.write_bytes(_png_bytes(samples, colour, depth, interlace, palette))
+            if depth == 8 and colour in (2, 6, 3, 0):   # the writer above against an independent reader
+                ref = np.asarray(Image.open(src).convert("RGB"))
+                assert np.array_equal(ref, want.astype(np.uint8)), ("writer", colour, depth, w, h)
+            subprocess.check_call([exe, "convert", str(src), str(dst)])
+            tok = dst.read_text().split()
+            assert tok[:4] == ["P3", str(w), str(h), "255"]
+            got = np.array(tok[4:], np.int64).reshape(h, w, 3)
+            assert np.array_equal(got, want), (colour, depth, w, h, interlace)
+
+
 def test_bitbuffer_escaping_and_padding():
     r = _selftest()
     # 16 one-bits escaped (two stuffed zeros), then 9 plain bits 1010 0101 1, zero padded
