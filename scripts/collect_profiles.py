@@ -14,8 +14,9 @@ import sys
 
 tag = sys.argv[1]
 src = "gpurun_out/final"
-names = {"16k_420_q90": "16k_420", "4k_444_q90": "4k_444", "batch_1080p_420_q90": "batch256"}
-launches = {"16k_420_q90": 1, "4k_444_q90": 1, "batch_1080p_420_q90": 2}
+names = {"16k_420_q90": "16k_420", "4k_444_q90": "4k_444", "batch_1080p_420_q90": "batch256",
+         "1080p_420_q90": "1080p_420", "8k_noise_q100_420": "8k_noise_420", "8k_noise_q100_444": "8k_noise_444"}
+launches = {wl: 2 if wl.startswith("batch_") else 1 for wl in names}
 traffic = {}
 for wl, short in names.items():
     stats = glob.glob("%s/stats_%s/*/*kernel_stats.csv" % (src, wl))

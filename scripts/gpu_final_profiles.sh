@@ -19,4 +19,15 @@ timeout -k 10 300 python3 bench.py > $OUT/bench_16k_default.json 2> $OUT/bench_1
 for WL in 4k_444_q90 batch_1080p_420_q90 1080p_420_q90 8k_noise_q100_420 8k_noise_q100_444; do
   timeout -k 10 300 python3 bench.py --workload $WL --no-cpu-baseline > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
 done
+# Kernel statistics and the two traffic passes for the remaining workloads.
+for WL in 1080p_420_q90 8k_noise_q100_420 8k_noise_q100_444; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$WL -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --pipelined-steps 0 --workload $WL > $OUT/stats_$WL.log 2>&1
+  grep '^{' $OUT/stats_$WL.log | tail -1 > $OUT/bench_line_$WL.json
+  for PASS in "fetch FETCH_SIZE" "write WRITE_SIZE"; do
+    set -- $PASS
+    NAME=$1; shift
+    timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_${WL}_$NAME -- python3 bench.py --pipelined-steps 0 --steps 2 --warmup 1 --no-cpu-baseline --workload $WL > $OUT/pmc_${WL}_$NAME.log 2>&1
+  done
+  echo "done $WL"
+done
 echo all done
