@@ -260,15 +260,15 @@ __device__ __forceinline__ u32 group_symbol_offset(const GroupFront& f, int j, i
 // and additions to one LDS address queue up one behind the other, so every counter exists
 // kHistCopies times, side by side (on different banks), and a lane adds to the copy of its number
 // (16384 x 16384 4:2:0: 211 us with one copy, 196 with two, 191 with four or eight).
-constexpr int kHistTileBlocks = 128;   // its groups always fit the list (kGrpMaxItems)
-static_assert(kHistTileBlocks * 8 <= kGrpMaxItems, "a tile's groups have to fit the list");
+constexpr int kHistTileBlocks = 256;              // four blocks per lane while the list is made
+constexpr int kHistMaxItems = kHistTileBlocks * 8;   // a list of the pass's own: every group of a tile fits
 
 template <int kHistCopies>
 __global__ __launch_bounds__(256) void k_histogram_tiles(KGeom g, const int16_t* __restrict__ coef, u64* __restrict__ hist,
                                                          HistogramExport ex) {
     // AC-Y, AC-C: 256 counters each, then DC-Y, DC-C: 16 each; kHistCopies of everything.
     __shared__ u32 cnt[(2 * 256 + 2 * 16) * kHistCopies];
-    __shared__ unsigned short items[4][kGrpMaxItems + 2];
+    __shared__ unsigned short items[4][kHistMaxItems + 2];
     u32* lh = (u32*)&items[0][0];   // at the end: the sums, laid out as flush_histograms expects them (DC-Y, DC-C, AC-Y, AC-C)
     static_assert(sizeof(items) >= 4 * 256 * sizeof(u32), "the sums take the lists' place");
     __shared__ unsigned char roleTab[4][kGrpTileBlocks];
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void k_histogram_tiles(KGeom g, const int16_t*
     const u32 tiles = ((u32)g.blocksPerImage + kHistTileBlocks - 1) / kHistTileBlocks;
     GroupTile t;
     t.items = items[wave];
-    t.cap = kGrpMaxItems;
+    t.cap = kHistMaxItems;
     t.role = roleTab[wave];
     for (u32 tile = blockIdx.x * 4u + (u32)wave; tile < tiles; tile += gridDim.x * 4u) {
         t.first = tile * kHistTileBlocks;
