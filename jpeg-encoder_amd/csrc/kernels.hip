@@ -307,17 +307,20 @@ __device__ __forceinline__ f2 unorm8_pair(u32 wa, u32 wb, int k) {
     return fma2(x, splat(INV255_HI), x * INV255_LO);
 }
 
-// The colour matrix (SIMD256.h:155-186) on the same pixel of two rows.
+// The colour matrix (SIMD256.h:155-186) on the same pixel of two rows.  A product with 0.5 is
+// exact, so "t + 0.5 * b" rounds once, like fma(b, 0.5, t): the two terms with the factor 0.5
+// take one instruction each instead of two (an input small enough for 0.5 * b to be inexact
+// changes a sum that the bias of 0.5 absorbs right after).
 __device__ __forceinline__ void ycbcr_pair(f2 r, f2 g, f2 b, f2& y, f2& cb, f2& cr) {
     f2 t = r * 0.2990f;
     t = t + g * 0.5870f;
     y = t + b * 0.1140f;
     t = r * -0.1687f;
     t = t + g * -0.3312f;
-    t = t + b * 0.5000f;
+    t = fma2(b, splat(0.5000f), t);
     cb = t + 0.5f;
-    t = r * 0.5000f;
-    t = t + g * -0.4186f;
+    const f2 u = g * -0.4186f;
+    t = fma2(r, splat(0.5000f), u);   // 0.5 * r + (-0.4186 * g), as t = 0.5 * r; t = t + -0.4186 * g
     t = t + b * -0.0813f;
     cr = t + 0.5f;
 }
@@ -526,11 +529,14 @@ __global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned c
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 // (a + b) / 2.0f across, both rows at once (SIMD256.h:260-277), then
-                // (row0 + row1) / 2.0f down (SIMD256.h:295-304).
-                const f2 hcb = (cb[2 * j] + cb[2 * j + 1]) * 0.5f;
-                const f2 hcr = (cr[2 * j] + cr[2 * j + 1]) * 0.5f;
-                ocb[j] = (hcb.x + hcb.y) * 0.5f;
-                ocr[j] = (hcr.x + hcr.y) * 0.5f;
+                // (row0 + row1) / 2.0f down (SIMD256.h:295-304).  Halving is exact and commutes
+                // with the rounding of the sum (byte pixels keep every term far from the ends of
+                // the exponent range): ((a + b) / 2 + (c + d) / 2) / 2 == ((a + b) + (c + d)) / 4,
+                // each sum rounded as before.
+                const f2 scb = cb[2 * j] + cb[2 * j + 1];
+                const f2 scr = cr[2 * j] + cr[2 * j + 1];
+                ocb[j] = (scb.x + scb.y) * 0.25f;
+                ocr[j] = (scr.x + scr.y) * 0.25f;
             }
             if ((rp & 1) == 0) {
 #pragma unroll
