@@ -194,12 +194,44 @@ def main():
     # timing reduction of this harness).  One communicator per image in flight.
     use_rccl = world > 1 and dist.get_backend() == "nccl"
 
-    def make_comm():
-        uid = torch.from_numpy(B.comm_unique_id()).to(dev) if rank == 0 else torch.zeros(128, dtype=torch.uint8, device=dev)
-        dist.broadcast(uid, 0)
-        return B.Communicator(uid.cpu().numpy(), rank, world, local_rank)
+    rccl_error = None
 
-    comms = [make_comm()] if use_rccl else [None]
+    def make_comm():
+        # Byte 128 says whether rank 0 got an id at all, so that no rank waits for a broadcast
+        # that never comes.
+        msg = torch.zeros(129, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            try:
+                msg[:128] = torch.from_numpy(B.comm_unique_id()).to(dev)
+                msg[128] = 1
+            except Exception as e:      # reported below, through the fall-back
+                print("bench.py: no RCCL id: %s: %s" % (type(e).__name__, e), file=sys.stderr)
+        dist.broadcast(msg, 0)
+        host = msg.cpu().numpy()
+        if host[128] != 1:
+            raise RuntimeError("rank 0 could not create an RCCL id")
+        return B.Communicator(host[:128], rank, world, local_rank)
+
+    comms = [None]
+    if use_rccl:
+        # If the library's own communicator cannot be set up on every rank, all ranks fall back
+        # together to torch.distributed's all-reduce of the histograms (the same exchange through
+        # another RCCL communicator) and the line says so.
+        try:
+            comms = [make_comm()]
+            ok = 1
+        except Exception as e:
+            rccl_error = "%s: %s" % (type(e).__name__, e)
+            ok = 0
+        agreed = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0:
+            for c in comms:
+                if c is not None:
+                    c.close()
+            comms = [None]
+            use_rccl = False
+            rccl_error = rccl_error or "another rank could not create its communicator"
     # What the exchange step ran on; with one rank there is none (the image is one band).
     collective = {"backend": "none (one rank, no exchange step)", "world_size": 1,
                   "devices": [torch.cuda.get_device_name(local_rank)]}
@@ -208,7 +240,10 @@ def main():
         dist.all_gather_object(names, "cuda:%d %s" % (local_rank, torch.cuda.get_device_name(local_rank)))
         collective = {"backend": "rccl: ncclAllReduce of uint64[4][256] on the encoder's stream (libjpegenc_hip), "
                                  "torch.distributed backend %s for set-up and timing" % dist.get_backend()
-                      if use_rccl else "%s through host memory (rehearsal)" % dist.get_backend(),
+                      if use_rccl else
+                      ("torch.distributed all_reduce of uint64[4][256] (backend nccl = RCCL) ordered against the encoder's "
+                       "stream; the library's own communicator failed: %s" % rccl_error
+                       if dist.get_backend() == "nccl" else "%s through host memory (rehearsal)" % dist.get_backend()),
                       "world_size": dist.get_world_size(), "devices": names}
 
     width, height, sname, quality, kind, desc = WORKLOADS[args.workload]
