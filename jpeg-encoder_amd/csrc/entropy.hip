@@ -578,8 +578,11 @@ static long long histogram_tiles_min_blocks() {
 static hipError_t launch_histogram_tiles(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, HistogramExport* ex) {
     const long long tilesPerImage = (g.blocksPerImage + kHistTileBlocks - 1) / kHistTileBlocks;
     long long grid = (tilesPerImage + 3) / 4;
-    // Five workgroups per CU: measured best for the 16384 x 16384 image (1024: 199 us, 1280: 191, 2048: 195).
-    const long long cap = g.batch > 1 ? (4096 / g.batch > 8 ? 4096 / g.batch : 8) : 1280;
+    // Five workgroups per CU: measured best for the 16384 x 16384 image (tiles of 128 blocks: 1024 workgroups
+    // 199 us, 1280: 191, 2048: 195; tiles of 256: 768: 190, 1024: 186, 1280: 182, 1536: 186, 2048: 207).
+    // (Diagnostic switch JPEGENC_HIST_GRID: another number.)
+    static const long long gridCap = getenv("JPEGENC_HIST_GRID") ? atoll(getenv("JPEGENC_HIST_GRID")) : 1280;
+    const long long cap = g.batch > 1 ? (4096 / g.batch > 8 ? 4096 / g.batch : 8) : gridCap;
     if (grid > cap) grid = cap;
     HistogramExport none = {nullptr, 0, nullptr};
     if (ex != nullptr) ex->expected += (unsigned long long)grid;
