@@ -349,6 +349,71 @@ __device__ __forceinline__ u32 ff_bits(u32 w) {   // bit k: byte k of w is 0xFF
     return ((t & 0x01010101u) * 0x01020408u) >> 24;
 }
 
+// ORs v into a word of the (zero-initialised) stream that other writers may OR into as well, and
+// keeps the chunk's count of 0xFF bytes right: every writer adds what its own OR changed (the
+// bytes that are 0xFF behind it minus those that were before), which adds up to the count of the
+// finished word whatever the order.
+__device__ __forceinline__ void or_counted(u32* __restrict__ words, u64 index, u32 v, u32* __restrict__ ffCount) {
+    const u32 old = atomicOr(&words[index], v);
+    const u32 n = (u32)__popc(ff_bits(old | v)) - (u32)__popc(ff_bits(old));
+    if (n != 0) atomicAdd(&ffCount[index >> kChunkWordShift], n);
+}
+
+// A workgroup's staged words (native order, word 0 = stream word wordBase) go to the stream byte
+// swapped: every wave takes a contiguous quarter, 64 consecutive words per instruction.  The first
+// and the last word may be shared with the neighbouring tiles and are merged.  ffCount (may be
+// null): the 0xFF bytes of the words are added to their chunks' counts on the way (see
+// kChunkCountMask), one addition per wave and chunk.
+__device__ __forceinline__ void copy_out_counted(const u32* stage, u32 nWords, u64 wordBase, u32* __restrict__ words,
+                                                 u32* __restrict__ ffCount) {
+    const int lane = threadIdx.x & 63;
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u32 quarter = (nWords + 3u) / 4u;
+    const u32 begin = wave * quarter;
+    const u32 end = begin + quarter < nWords ? begin + quarter : nWords;
+    if (begin >= end) return;
+    u64 curChunk = (wordBase + begin) >> kChunkWordShift;
+    u32 acc = 0;
+    auto flush = [&](u32 mine) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mine += (u32)__shfl_xor((int)mine, d, 64);
+        if (lane == 0 && mine != 0) atomicAdd(&ffCount[curChunk], mine);
+    };
+    for (u32 base = begin; base < end; base += 64u) {
+        const u32 i = base + (u32)lane;
+        u32 n = 0;
+        bool inCur = true;
+        if (i < end) {
+            const u32 v = __builtin_bswap32(stage[i]);
+            const u64 at = wordBase + i;
+            if (i == 0 || i == nWords - 1u) {
+                if (v != 0) {
+                    if (ffCount != nullptr) {
+                        const u32 old = atomicOr(&words[at], v);
+                        n = (u32)__popc(ff_bits(old | v)) - (u32)__popc(ff_bits(old));
+                    } else {
+                        atomicOr(&words[at], v);
+                    }
+                }
+            } else {
+                words[at] = v;
+                n = (u32)__popc(ff_bits(v));
+            }
+            inCur = (at >> kChunkWordShift) == curChunk;
+        }
+        if (ffCount == nullptr) continue;
+        const u32 last = base + 63u < end ? base + 63u : end - 1u;
+        const u64 lastChunk = (wordBase + last) >> kChunkWordShift;   // the same for the whole wave
+        if (lastChunk == curChunk) {
+            acc += n;
+        } else {   // a chunk ends inside these 64 words (at most one does)
+            flush(acc + (inCur ? n : 0u));
+            acc = inCur ? 0u : n;
+            curChunk = lastChunk;
+        }
+    }
+    if (ffCount != nullptr) flush(acc);
+}
 
 // ---- restart intervals -------------------------------------------------------------------
 // The unstuffed stream holds, per interval, an RSTn marker (every interval but the image's
@@ -376,12 +441,24 @@ constexpr int kEmitStageShort = 2048;   // stage words of a tile of short blocks
 constexpr int kEmitStageLong = 6144;    // ... of long blocks (up to 96 bytes per block on average)
 
 // Where a lane's bits go: the LDS stage (native order) or the global stream (swapped).
-struct BitTarget {
+template <bool kCount>
+struct BitTargetT {
     u32* words;
     long long bias;   // index of the stream word that words[0] stands for
     bool swap;
+    u32* ff;          // per-chunk 0xFF counts to keep up to date when the target is the stream itself, or null
     __device__ __forceinline__ void or_word(long long index, u32 v) const {
-        if (v != 0) atomicOr(&words[index - bias], swap ? __builtin_bswap32(v) : v);
+        if (v == 0) return;
+        if (kCount && swap && ff != nullptr) or_counted(words, (u64)index, __builtin_bswap32(v), ff);
+        else atomicOr(&words[index - bias], swap ? __builtin_bswap32(v) : v);
+    }
+    // A whole word of the stream that belongs to the caller alone.
+    __device__ __forceinline__ void store_word(long long index, u32 v) const {
+        words[index - bias] = swap ? __builtin_bswap32(v) : v;
+        if (kCount && swap && ff != nullptr) {
+            const u32 n = (u32)__popc(ff_bits(v));
+            if (n != 0) atomicAdd(&ff[(u64)index >> kChunkWordShift], n);
+        }
     }
     // ORs up to 32 bits, given left aligned in v, into the stream at bit position pos.
     __device__ __forceinline__ void or32(u64 pos, u32 v) const {
@@ -436,10 +513,11 @@ struct PrivateVisitor {
 };
 
 // Second walk, for the blocks that did not fit their private words: straight to the target.
+template <bool kCount>
 struct EmitVisitor {
     const u32* dcTab;
     const u32* acTab;
-    BitTarget out;
+    BitTargetT<kCount> out;
     long long word;   // index of the word being filled
     u64 acc;          // pending bits, right aligned
     int n;            // number of pending bits (< 32 between calls)
@@ -450,7 +528,7 @@ struct EmitVisitor {
             out.or_word(word, w);
             first = false;
         } else {
-            out.words[word - out.bias] = out.swap ? __builtin_bswap32(w) : w;
+            out.store_word(word, w);
         }
         ++word;
         n -= 32;
@@ -646,7 +724,12 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
                                                              const u32* __restrict__ tables, u64* __restrict__ state,
                                                              u64* __restrict__ ivOff, u64* __restrict__ result,
                                                              u32* __restrict__ words, u64* __restrict__ hostResult,
-                                                             long long zeroedBytes) {
+                                                             long long zeroedBytes, u32* __restrict__ ffCount) {
+    // ffCount (may be null): per-chunk counts of the stream's 0xFF bytes (zero at the start), kept up
+    // to date as the words are written, so that no counting pass has to read the stream again.  It
+    // pays for short blocks (1080p: entropy stage 39 -> 34 us); for long ones the counting costs
+    // this kernel more instructions than the pass of its own takes (8192 x 8192 noise 4:4:4: + 95 us
+    // against the pass's 44), so they are launched without.
     __shared__ u32 tab[4 * 256];
     constexpr int kStageWords = kPrivate ? kEmitStageShort : kEmitStageLong;
     __shared__ u32 stage[kStageWords];
@@ -809,9 +892,12 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
         __syncthreads();
     }
     if (active) {
-        const BitTarget out{staged ? stage : words, staged ? (long long)wordBase : 0, !staged};
+        const BitTargetT<kPrivate> out{staged ? stage : words, staged ? (long long)wordBase : 0, !staged, ffCount};
         const u64 start = pos + (leadMarker ? 16 : 0);   // first bit of the block itself
-        if (leadMarker) out.or32(pos, leadMarker << 16);
+        if (leadMarker) {
+            out.or32(pos, leadMarker << 16);
+            if (kPrivate && ffCount != nullptr) atomicAdd(&ffCount[pos >> 15], kChunkMarkerDelta);   // the marker's 0xFF is no data (bit position -> 4 KiB chunk)
+        }
         if (bits == 0) {
             // a block with a symbol that has no code: flagged above
         } else if (kPrivate && bits <= (u32)(kPrivWords * 32)) {
@@ -821,21 +907,28 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
                 if ((u32)(32 * k) < bits) out.or32(start + 32 * k, mine32[k]);
         } else {
             const int t = c == 0 ? 0 : 1;
-            EmitVisitor vis{tab + 256 * t, tab + 512 + 256 * t, out, (long long)(start >> 5), 0, (int)(start & 31), true};
+            EmitVisitor<kPrivate> vis{tab + 256 * t, tab + 512 + 256 * t, out, (long long)(start >> 5), 0, (int)(start & 31), true};
             walk_block(w, pred, vis);
             vis.finish();
         }
         if (padBits != 0 && g.padOnes) out.or32(start + bits, ((1u << padBits) - 1u) << (32 - padBits));
-        if (tailEoi) out.or32(start + bits + padBits, 0xffd9u << 16);
+        if (tailEoi) {
+            out.or32(start + bits + padBits, 0xffd9u << 16);
+            if (kPrivate && ffCount != nullptr) atomicAdd(&ffCount[(start + bits + padBits) >> 15], kChunkMarkerDelta);
+        }
     }
     if (staged) {
         __syncthreads();
-        for (u32 i = threadIdx.x; i < (u32)nWords; i += kEntThreads) {
-            const u32 v = __builtin_bswap32(stage[i]);
-            if (i == 0 || i == (u32)nWords - 1) {
-                if (v != 0) atomicOr(&words[wordBase + i], v);
-            } else {
-                words[wordBase + i] = v;
+        if (kPrivate && ffCount != nullptr) {
+            copy_out_counted(stage, (u32)nWords, wordBase, words, ffCount);
+        } else {
+            for (u32 i = threadIdx.x; i < (u32)nWords; i += kEntThreads) {
+                const u32 v = __builtin_bswap32(stage[i]);
+                if (i == 0 || i == (u32)nWords - 1) {
+                    if (v != 0) atomicOr(&words[wordBase + i], v);
+                } else {
+                    words[wordBase + i] = v;
+                }
             }
         }
     }
@@ -1225,6 +1318,10 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     // word of the stream exactly once, with plain stores.)
     const bool deferred = !fromRecords && groups && ws.tileSlots != nullptr && ws.groupTile == kGrpTileBlocks;
     const long long clear16 = deferred ? 0 : zero / 16;
+    // Who keeps the per-chunk counts of 0xFF bytes: the kernels that write the stream (deferred
+    // placement, the one-lane-per-block writer), or a pass of its own behind them.
+    const bool shortBlocks = ws.avgBlockBits <= 128;   // long blocks (noise, q=100) do not fit the private words; unknown lengths count as short
+    const bool counted = deferred || (!fromRecords && (groups || shortBlocks));
     long long prepGrid = (clear16 > tileCount / 2 ? clear16 : tileCount / 2) / (256 * 4);
     prepGrid = prepGrid < 1 ? 1 : (prepGrid > 2048 ? 2048 : prepGrid);
     // Chunks the stream can have at most: from the bound that was cleared.
@@ -1232,9 +1329,7 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     if (chunkBound > ws.maxChunks) chunkBound = ws.maxChunks;
     hipLaunchKernelGGL(k_prepare_entropy, dim3((unsigned)prepGrid), dim3(256), 0, s, (uint4*)ws.unstuffed, clear16,
                        ws.tileState, tileCount + 1, ws.result, ws.header, bo ? 0 : ws.headerLen, d_out,
-                       bo ? nullptr : ws.pendingTables, const_cast<u32*>(d_tables), ws.ffCount, deferred ? chunkBound : 0);
-    // Long blocks (noise, q=100) do not fit the private words; unknown lengths count as short.
-    const bool shortBlocks = ws.avgBlockBits <= 128;
+                       bo ? nullptr : ws.pendingTables, const_cast<u32*>(d_tables), ws.ffCount, counted ? chunkBound : 0);
     if (fromRecords) {
         hipLaunchKernelGGL(k_record_lengths, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, ws.records, ws.recCount + 1,
                            ws.recCount, ws.recGeneration, d_tables, ws.tileState, ws.result);
@@ -1252,7 +1347,7 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
         // tile starts, a third puts the bits there (a tile that chains with a look-back spends a
         // quarter of its life waiting for the slowest of the thousands of tiles in front of it).
         hipLaunchKernelGGL(k_encode_groups<true>, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, d_coef, d_tables,
-                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero, ws.tileSlots);
+                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero, ws.tileSlots, nullptr);
         const u32 runs = (u32)((tileCount + 63) / 64);
         u64* runStart = ws.tileState + tileCount;   // (the buffer is sized for tiles of 16 blocks)
         hipLaunchKernelGGL(k_group_positions, dim3(runs), dim3(64), 0, s, ws.tileState, runStart, (u32)tileCount);
@@ -1263,13 +1358,15 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
                            (u32*)ws.unstuffed, (u32)tileCount, ws.ffCount);
     } else if (groups)
         hipLaunchKernelGGL(k_encode_groups<false>, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, d_coef, d_tables, ws.tileState,
-                           ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero, nullptr);
+                           ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero, nullptr, ws.ffCount);
     else if (shortBlocks)
         hipLaunchKernelGGL(k_encode_bits<true>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
-                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult, zero);
+                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult, zero,
+                           ws.ffCount);
     else
         hipLaunchKernelGGL(k_encode_bits<false>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
-                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult, zero);
+                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult, zero,
+                           nullptr);
     // As many workgroups as the device holds at once (five per CU): a workgroup's run of chunks is
     // one chain (a chunk's bytes are asked for while the chunk in front is worked on), a second
     // round of workgroups would start that chain all over.  (Diagnostic switch JPEGENC_STUFF_GRID.)
@@ -1279,8 +1376,8 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     if (chunkGrid < 1) chunkGrid = 1;
     long long countGrid = (chunkBound + 3) / 4;
     countGrid = countGrid < 1 ? 1 : (countGrid > 4096 ? 4096 : countGrid);
-    // (With deferred placement the placing kernels have counted the 0xFF bytes as they wrote them.)
-    if (!deferred)
+    // (Not when the kernels that wrote the stream have counted its 0xFF bytes on the way.)
+    if (!counted)
         hipLaunchKernelGGL(k_count_ff, dim3((unsigned)countGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.result,
                            ws.ffCount);
     // Up to this many chunks a workgroup adds the counts in front of its first chunk up

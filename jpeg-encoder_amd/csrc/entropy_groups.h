@@ -347,23 +347,59 @@ __device__ __forceinline__ void stage_put(u32* st, u32 pos, u32 bits, u32 n) {
 // Copies `bits` bits of the stage, starting at word srcWord, to the stream at bit position
 // dst, and (kClear) clears them in the stage.  The stream is zero where nothing has been
 // written yet; the first and the last word of the range may be shared with neighbours and are merged.
+// ffCount (may be null): the 0xFF bytes of the words are added to their chunks' counts on the way
+// (see kChunkCountMask), one addition per chunk; the shared words at the ends count what their OR
+// changed (or_counted).  Call with all lanes of the wave.
 template <bool kClear>
-__device__ __forceinline__ void stage_copy_out(u32* st, u32 srcWord, u32 bits, u64 dst, u32* __restrict__ words) {
+__device__ __forceinline__ void stage_copy_out(u32* st, u32 srcWord, u32 bits, u64 dst, u32* __restrict__ words,
+                                               u32* __restrict__ ffCount = nullptr) {
     if (bits == 0) return;
     const int lane = threadIdx.x & 63;
     const u32 s = (u32)(dst & 31);
     const u64 w0 = dst >> 5;
     const u32 nSrc = (bits + 31) >> 5, nOut = (s + bits + 31) >> 5;
-    for (u32 i = lane; i < nOut; i += 64) {
-        const u32 hi = i > 0 ? st[srcWord + i - 1] : 0u;
-        const u32 lo = i < nSrc ? st[srcWord + i] : 0u;
-        const u32 v = __builtin_bswap32(__builtin_amdgcn_alignbit(hi, lo, s));
-        if (i == 0 || i == nOut - 1) {
-            if (v != 0) atomicOr(&words[w0 + i], v);
-        } else {
-            words[w0 + i] = v;
+    u64 curChunk = w0 >> kChunkWordShift;
+    u32 acc = 0;
+    auto flush = [&](u32 mine) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mine += (u32)__shfl_xor((int)mine, d, 64);
+        if (lane == 0 && mine != 0) atomicAdd(&ffCount[curChunk], mine);
+    };
+    for (u32 base = 0; base < nOut; base += 64) {
+        const u32 i = base + (u32)lane;
+        u32 n = 0;
+        bool inCur = true;
+        if (i < nOut) {
+            const u32 hi = i > 0 ? st[srcWord + i - 1] : 0u;
+            const u32 lo = i < nSrc ? st[srcWord + i] : 0u;
+            const u32 v = __builtin_bswap32(__builtin_amdgcn_alignbit(hi, lo, s));
+            if (i == 0 || i == nOut - 1) {
+                if (v != 0) {
+                    if (ffCount != nullptr) {
+                        const u32 old = atomicOr(&words[w0 + i], v);
+                        n = (u32)__popc(ff_bits(old | v)) - (u32)__popc(ff_bits(old));
+                    } else {
+                        atomicOr(&words[w0 + i], v);
+                    }
+                }
+            } else {
+                words[w0 + i] = v;
+                n = (u32)__popc(ff_bits(v));
+            }
+            inCur = ((w0 + i) >> kChunkWordShift) == curChunk;
+        }
+        if (ffCount == nullptr) continue;
+        const u32 last = base + 63u < nOut ? base + 63u : nOut - 1u;
+        const u64 lastChunk = (w0 + last) >> kChunkWordShift;   // the same for the whole wave
+        if (lastChunk == curChunk) {
+            acc += n;
+        } else {   // a chunk ends inside these 64 words (at most one does)
+            flush(acc + (inCur ? n : 0u));
+            acc = inCur ? 0u : n;
+            curChunk = lastChunk;
         }
     }
+    if (ffCount != nullptr) flush(acc);
     if (kClear)
         for (u32 i = lane; i < nSrc; i += 64) st[srcWord + i] = 0;
 }
@@ -466,23 +502,25 @@ __device__ __forceinline__ void place_tile(const KGeom& g, u32* st, PosSummary w
     const bool frontDone = partWord != ~0u;
     if (!frontDone) partWord = (((h + 31u) & ~31u) + 32u) >> 5;
     u64* edges = (u64*)(st + kGrpSlotEdges);   // (slots only)
-    if (kClear) stage_copy_out<true>(st, 0, h, start, words);   // (kClear: the stage in LDS; otherwise a slot in memory)
+    if (kClear) stage_copy_out<true>(st, 0, h, start, words, ffCount);   // (kClear: the stage in LDS; otherwise a slot in memory)
     else if (!frontDone) slot_copy_out(st, 0, h, start, words, edges, ffCount);
     if (whole.x >> 31) {
         const u64 partStart = (start + h + 7) & ~7ull;
-        if (kClear) stage_copy_out<true>(st, partWord, whole.y, partStart, words);
+        if (kClear) stage_copy_out<true>(st, partWord, whole.y, partStart, words, ffCount);
         else slot_copy_out(st, partWord, whole.y, partStart, words, edges + 2, ffCount);
         if (kClear && g.padOnes && partStart != start + h && lane == 0) {   // the first end's padding, as one bits (slots: see slot_place)
             const u64 at = start + h;
             const u32 nPad = (u32)(partStart - at);
-            atomicOr(&words[at >> 5], __builtin_bswap32(((1u << nPad) - 1u) << (32u - (u32)(at & 31) - nPad)));
+            const u32 ones = __builtin_bswap32(((1u << nPad) - 1u) << (32u - (u32)(at & 31) - nPad));
+            if (ffCount != nullptr) or_counted(words, at >> 5, ones, ffCount);
+            else atomicOr(&words[at >> 5], ones);
         }
         if ((u32)lane < nFix && (u32)lane < (u32)kGrpMaxFix) {
             const u32 bl = fixBlock[lane];
             const long long iv = g.batch > 1 ? (long long)image : (long long)((bl / (u32)g.bpm) / (u32)g.mcusPerInterval);
             const u64 bytes = (partStart + fixRel[lane]) >> 3;
             ivOff[iv + 1] = bytes;
-            if (!kClear && ffCount != nullptr) {
+            if (ffCount != nullptr) {
                 // The markers at this interval's end are no data: EOI in front of `bytes` (the image
                 // ends), or the next interval's RSTn at `bytes`.
                 const bool lastOne = g.batch > 1 || iv + 1 == g.intervals;
@@ -506,7 +544,9 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
                                                        const u32* __restrict__ tables, u64* __restrict__ state,
                                                        u64* __restrict__ ivOff, u64* __restrict__ result,
                                                        u32* __restrict__ words, int tileBlocks, long long zeroedBytes,
-                                                       u32* __restrict__ slots) {
+                                                       u32* __restrict__ slots, u32* __restrict__ ffCount) {
+    // ffCount (tiles that place their bits themselves; may be null): per-chunk counts of the stream's
+    // 0xFF bytes, zero at the start, kept up to date as the words are written.
     __shared__ u32 tab[kTabWords];
     __shared__ unsigned short items[4][kGrpMaxItems + 2];
     __shared__ unsigned char roleTab[4][kGrpTileBlocks];
@@ -773,10 +813,19 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
     if (lane == 0)
         __hip_atomic_store(state + tile, kTilePosition | pos_apply(whole, start), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!ok) flags |= 2u;
-    place_tile<true>(g, st, whole, start, nFix, fixBlock[wave], fixRel[wave], image, ivOff, result, words, zeroedBytes);
+    place_tile<true>(g, st, whole, start, nFix, fixBlock[wave], fixRel[wave], image, ivOff, result, words, zeroedBytes, ~0u,
+                     ffCount);
     if (tile == 0 && lane == 0) {
         ivOff[0] = 0;
-        if (p0 != 0) atomicOr(&words[0], __builtin_bswap32((0xffd0u + (u32)((g.firstInterval - 1) & 7)) << 16));
+        if (p0 != 0) {   // the band does not start the image: its first interval's RSTn
+            const u32 mark = __builtin_bswap32((0xffd0u + (u32)((g.firstInterval - 1) & 7)) << 16);
+            if (ffCount != nullptr) {
+                or_counted(words, 0, mark, ffCount);
+                atomicAdd(&ffCount[0], kChunkMarkerDelta);
+            } else {
+                atomicOr(&words[0], mark);
+            }
+        }
     }
     if (flags != 0 && lane == 0) atomicOr((unsigned long long*)&result[1], (unsigned long long)flags);
 }
