@@ -644,12 +644,11 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
             tok[j] = e | __builtin_amdgcn_ubfe(amp[j >> 1], 16 * (j & 1), (u32)cat);
             off[j + 1] = off[j] + (tok[j] >> 27);
         }
-        {   // a token of the "no code" kind is larger than any other
-            const u32 m0 = tok[0] > tok[1] ? tok[0] : tok[1], m1 = tok[2] > tok[3] ? tok[2] : tok[3];
-            const u32 m2 = tok[4] > tok[5] ? tok[4] : tok[5], m3 = tok[6] > tok[7] ? tok[6] : tok[7];
-            const u32 m01 = m0 > m1 ? m0 : m1, m23 = m2 > m3 ? m2 : m3;
-            const u32 m = m01 > m23 ? m01 : m23;
-            maxTok = m > maxTok ? m : maxTok;
+        {   // a token of the "no code" kind is larger than any other (four v_max3_u32)
+            u32 m = max(max(maxTok, tok[0]), tok[1]);
+            m = max(max(m, tok[2]), tok[3]);
+            m = max(max(m, tok[4]), tok[5]);
+            maxTok = max(max(m, tok[6]), tok[7]);
         }
         if (f.zr != 0 && zrlTok > maxTok) maxTok = zrlTok;
         if (f.needEob && eobTok > maxTok) maxTok = eobTok;
