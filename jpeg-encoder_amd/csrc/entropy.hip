@@ -643,14 +643,14 @@ __device__ __forceinline__ bool look_back(const u64* state, long long tile, u64 
 
 #include "entropy_groups.h"
 
-// It pays from about half a million blocks on (3840 x 2160 4:4:4, 0.39 million: 30 us against the 29 of
-// k_histogram; an eighth of the 16384 x 16384 image, 0.79 million: 36 against 41; 8192 x 8192 4:2:0 noise,
-// 1.6 million: 99 against 117; 16384 x 16384: 189 against 208).
+// It pays from about a quarter of a million blocks on (tiles of 256 blocks, natural content, against
+// k_histogram: 49 k blocks 19 against 13 us, 98 k 20 against 17, 197 k 21 against 20, 393 k 23 against 29,
+// 0.79 million 36 against 41, 6.3 million 181 against 208; 8192 x 8192 4:2:0 noise, 1.6 million: 99 against 117).
 // (Diagnostic switch JPEGENC_HIST_TILES_MIN_BLOCKS: another threshold, read at every call so that a
 // test can set it.)
 static long long histogram_tiles_min_blocks() {
     const char* env = getenv("JPEGENC_HIST_TILES_MIN_BLOCKS");
-    return env ? atoll(env) : 500000;
+    return env ? atoll(env) : 250000;
 }
 
 static hipError_t launch_histogram_tiles(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, HistogramExport* ex) {
