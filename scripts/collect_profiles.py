@@ -19,18 +19,19 @@ names = {"16k_420_q90": "16k_420", "4k_444_q90": "4k_444", "batch_1080p_420_q90"
 launches = {wl: 2 if wl.startswith("batch_") else 1 for wl in names}
 traffic = {}
 for wl, short in names.items():
-    stats = glob.glob("%s/stats_%s/*/*kernel_stats.csv" % (src, wl))
+    # (a directory may hold earlier runs as well: the newest file counts)
+    stats = sorted(glob.glob("%s/stats_%s/*/*kernel_stats.csv" % (src, wl)), key=os.path.getmtime)
     if stats:
-        shutil.copy(stats[0], "profiles/%s_%s_kernel_stats.csv" % (tag, short))
+        shutil.copy(stats[-1], "profiles/%s_%s_kernel_stats.csv" % (tag, short))
     line = "%s/bench_line_%s.json" % (src, wl)
     if os.path.exists(line) and os.path.getsize(line) > 0:
         shutil.copy(line, "profiles/%s_%s_bench_line.json" % (tag, short))
     per_kernel = {}
     for pas in ("fetch", "write", "sq", "sq2"):
-        found = glob.glob("%s/pmc_%s_%s/*/*counter_collection.csv" % (src, wl, pas))
+        found = sorted(glob.glob("%s/pmc_%s_%s/*/*counter_collection.csv" % (src, wl, pas)), key=os.path.getmtime)
         if not found:
             continue
-        rows = [r for r in csv.DictReader(open(found[0])) if "jpeghip" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(found[-1])) if "jpeghip" in r["Kernel_Name"]]
         if not rows:
             continue
         with open("profiles/%s_%s_pmc_%s.csv" % (tag, short, pas), "w", newline="") as f:
