@@ -1083,7 +1083,12 @@ __device__ __forceinline__ long long batch_position(const BatchOutput& bo, const
     return k * bo.slotBytes + (long long)bo.hdrLen[k] + (long long)(i - ivOff[k]) + (long long)(ffBefore - bo.ffStart[k]);
 }
 
-template <bool kBatch>
+// kOwnBytes: a lane stores exactly its own output bytes, at whatever address they begin (the target
+// takes unaligned stores), instead of the aligned dwords that begin among them -- fewer instructions,
+// which is what a long stream is bound by (16384 x 16384: 42.5 -> 38.8 us, 8192 x 8192 noise 4:4:4:
+// 133 -> 108 us), but a longer way through a single chunk (1080p: 6.9 -> 11.4 us), so short streams
+// keep the other form.
+template <bool kBatch, bool kOwnBytes>
 __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __restrict__ buf,
                                                      const u64* __restrict__ ivOff, const u32* __restrict__ ffCount,
                                                      const u64* __restrict__ groupSum, u64* __restrict__ result,
@@ -1114,7 +1119,7 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
         qNext = make_uint4(0, 0, 0, 0);
         eNext = 0;
         if ((u64)i0 < bytes) qNext = *(const uint4*)(buf + i0);
-        if ((u64)i0 + 16 < bytes) eNext = *(const u32*)(buf + i0 + 16);
+        if (!kOwnBytes && (u64)i0 + 16 < bytes) eNext = *(const u32*)(buf + i0 + 16);
         // does a marker begin in this chunk, or (bit 1) in the next one, where the last lane's four bytes lie
         flagsNext = (ffCount[ch] > kChunkCountMask ? 1u : 0u) | (ch + 1 < chunks && ffCount[ch + 1] > kChunkCountMask ? 2u : 0u);
     };
@@ -1154,51 +1159,90 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
                     if (hostResult) hostResult[1] = 1;
                 }
             } else if (valid > 0) {
-                // The lane's output as a string of bytes in registers: its sixteen bytes, then the
-                // four that follow them in the stream (the lane owns every output dword that
-                // begins among its own bytes, and such a dword may end among its successor's),
-                // with a zero byte inserted behind every 0xFF that is data.
-                u32 str[9] = {q.x, q.y, q.z, q.w, 0u, 0u, 0u, 0u, 0u};
-                u32 todo = mask;
-                if ((u64)i0 + 16 < bytes) {
-                    str[4] = e;
-                    u32 ef = ff_bits(e) & 7u;
-                    const bool mayHold = (flags >> (threadIdx.x == 255 ? 1 : 0)) & 1u;   // a marker may begin among these bytes
-                    for (u32 t = ef; t != 0; t &= t - 1) {
-                        const int j = __builtin_ctz(t);
-                        const uint8_t nxt = (uint8_t)(e >> (8 * (j + 1)));
-                        if ((u64)i0 + 16 + j >= bytes || (mayHold && is_marker_ff(g, ivOff, bytes, (u64)(i0 + 16 + j), nxt))) ef &= ~(1u << j);
-                    }
-                    todo |= ef << 16;
-                }
-                for (u32 inserted = 0; todo != 0; todo &= todo - 1, ++inserted) {
-                    const u32 z = (u32)__builtin_ctz(todo) + inserted + 1;   // index the zero byte gets
-                    const u32 w = z >> 2, r = z & 3u;
-                    const u32 keep = (1u << (8 * r)) - 1u, above = 0xffffff00u << (8 * r);
+                if (kOwnBytes) {
+                    // The lane's output as a string of bytes in registers: its sixteen bytes with a zero
+                    // byte inserted behind every 0xFF that is data, stored at its own byte position
+                    // (stores to memory need no alignment on this target, so no lane has to know its
+                    // neighbours' bytes).
+                    u32 str[8] = {q.x, q.y, q.z, q.w, 0u, 0u, 0u, 0u};
+                    u32 inserted = 0;
+                    for (u32 todo = mask; todo != 0; todo &= todo - 1, ++inserted) {
+                        const u32 z = (u32)__builtin_ctz(todo) + inserted + 1;   // index the zero byte gets
+                        const u32 w = z >> 2, r = z & 3u;
+                        const u32 keep = (1u << (8 * r)) - 1u, above = 0xffffff00u << (8 * r);
 #pragma unroll
-                    for (int i = 8; i >= 0; --i) {   // bytes from z on move up by one
-                        const u32 up = i > 0 ? __builtin_amdgcn_alignbyte(str[i], str[i > 0 ? i - 1 : 0], 3) : str[0] << 8;
-                        if ((u32)i > w) str[i] = up;
-                        else if ((u32)i == w) str[i] = (str[i] & keep) | (up & above);
+                        for (int i = 7; i >= 0; --i) {   // bytes from z on move up by one
+                            const u32 up = i > 0 ? __builtin_amdgcn_alignbyte(str[i], str[i > 0 ? i - 1 : 0], 3) : str[0] << 8;
+                            if ((u32)i > w) str[i] = up;
+                            else if ((u32)i == w) str[i] = (str[i] & keep) | (up & above);
+                        }
                     }
-                }
-                const u32 nOut = (u32)valid + (u32)__popc(mask);
-                const long long mine = base + (long long)local, chunkEnd = base + (long long)total;
-                uint8_t* dst = out + mine;
-                const u32 a = (u32)(-(long long)(uintptr_t)dst) & 3u;   // bytes in front of the first dword that begins here
-                // The chunk's first bytes up to a dword boundary (the dword belongs to another
-                // chunk, or to the header): byte by byte.
-                if (threadIdx.x == 0)
-                    for (u32 b = 0; b < a && b < nOut; ++b) dst[b] = (uint8_t)(str[0] >> (8 * b));
+                    uint8_t* dst = out + base + (long long)local;
+                    // byte b of the string, for the few bytes that are not stored as whole words
+                    auto byte_at = [&](u32 b) {
+                        const u32 i = b >> 2;
+                        const u32 lo4 = i & 2u ? (i & 1u ? str[3] : str[2]) : (i & 1u ? str[1] : str[0]);
+                        const u32 hi4 = i & 2u ? (i & 1u ? str[7] : str[6]) : (i & 1u ? str[5] : str[4]);
+                        return (uint8_t)((i & 4u ? hi4 : lo4) >> (8 * (b & 3u)));
+                    };
+                    if (valid == 16) {
+                        const uint4 first = make_uint4(str[0], str[1], str[2], str[3]);
+                        __builtin_memcpy(dst, &first, 16);
+                        // what the insertions pushed out of the first sixteen bytes: one byte as a rule
+                        if (inserted != 0) {
+                            dst[16] = (uint8_t)str[4];
+                            for (u32 b = 17; b < 16u + inserted; ++b) dst[b] = byte_at(b);
+                        }
+                    } else {   // the stream's last bytes
+                        for (u32 b = 0; b < (u32)valid + inserted; ++b) dst[b] = byte_at(b);
+                    }
+                } else {
+                    // The lane's output as a string of bytes in registers: its sixteen bytes, then the
+                    // four that follow them in the stream (the lane owns every output dword that
+                    // begins among its own bytes, and such a dword may end among its successor's),
+                    // with a zero byte inserted behind every 0xFF that is data.
+                    u32 str[9] = {q.x, q.y, q.z, q.w, 0u, 0u, 0u, 0u, 0u};
+                    u32 todo = mask;
+                    if ((u64)i0 + 16 < bytes) {
+                        str[4] = e;
+                        u32 ef = ff_bits(e) & 7u;
+                        const bool mayHold = (flags >> (threadIdx.x == 255 ? 1 : 0)) & 1u;   // a marker may begin among these bytes
+                        for (u32 t = ef; t != 0; t &= t - 1) {
+                            const int j = __builtin_ctz(t);
+                            const uint8_t nxt = (uint8_t)(e >> (8 * (j + 1)));
+                            if ((u64)i0 + 16 + j >= bytes || (mayHold && is_marker_ff(g, ivOff, bytes, (u64)(i0 + 16 + j), nxt))) ef &= ~(1u << j);
+                        }
+                        todo |= ef << 16;
+                    }
+                    for (u32 inserted = 0; todo != 0; todo &= todo - 1, ++inserted) {
+                        const u32 z = (u32)__builtin_ctz(todo) + inserted + 1;   // index the zero byte gets
+                        const u32 w = z >> 2, r = z & 3u;
+                        const u32 keep = (1u << (8 * r)) - 1u, above = 0xffffff00u << (8 * r);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const u32 off = a + 4u * i;
-                    if (off < nOut) {
-                        const u32 v = __builtin_amdgcn_alignbyte(str[i + 1], str[i], a);
-                        if (mine + off + 4 <= chunkEnd) {
-                            *(u32*)(dst + off) = v;
-                        } else {   // the chunk ends inside this dword
-                            for (u32 b = 0; mine + off + b < chunkEnd; ++b) dst[off + b] = (uint8_t)(v >> (8 * b));
+                        for (int i = 8; i >= 0; --i) {   // bytes from z on move up by one
+                            const u32 up = i > 0 ? __builtin_amdgcn_alignbyte(str[i], str[i > 0 ? i - 1 : 0], 3) : str[0] << 8;
+                            if ((u32)i > w) str[i] = up;
+                            else if ((u32)i == w) str[i] = (str[i] & keep) | (up & above);
+                        }
+                    }
+                    const u32 nOut = (u32)valid + (u32)__popc(mask);
+                    const long long mine = base + (long long)local, chunkEnd = base + (long long)total;
+                    uint8_t* dst = out + mine;
+                    const u32 a = (u32)(-(long long)(uintptr_t)dst) & 3u;   // bytes in front of the first dword that begins here
+                    // The chunk's first bytes up to a dword boundary (the dword belongs to another
+                    // chunk, or to the header): byte by byte.
+                    if (threadIdx.x == 0)
+                        for (u32 b = 0; b < a && b < nOut; ++b) dst[b] = (uint8_t)(str[0] >> (8 * b));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const u32 off = a + 4u * i;
+                        if (off < nOut) {
+                            const u32 v = __builtin_amdgcn_alignbyte(str[i + 1], str[i], a);
+                            if (mine + off + 4 <= chunkEnd) {
+                                *(u32*)(dst + off) = v;
+                            } else {   // the chunk ends inside this dword
+                                for (u32 b = 0; mine + off + b < chunkEnd; ++b) dst[off + b] = (uint8_t)(v >> (8 * b));
+                            }
                         }
                     }
                 }
@@ -1389,16 +1433,28 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
                            ws.groupSum);
         groupSum = ws.groupSum;
     }
+    // Streams of several chunks per workgroup store every lane's own bytes (see k_stuff_bytes).
+    // (Diagnostic switch JPEGENC_STUFF_FORM=0 / 1: always the aligned form / always the other.)
+    static const char* stuffForm = getenv("JPEGENC_STUFF_FORM");
+    const bool ownBytes = stuffForm ? stuffForm[0] == '1' : chunkBound >= 4 * gridCap;
     if (bo) {
         hipLaunchKernelGGL(k_image_ff_start, dim3((unsigned)(g.batch + 1)), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
                            ws.ffCount, groupSum, ws.result, bo->ffStart);
         hipLaunchKernelGGL(k_copy_headers, dim3((unsigned)g.batch), dim3(256), 0, s, *bo);
-        hipLaunchKernelGGL(k_stuff_bytes<true>, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
-                           ws.ffCount, groupSum, ws.result, bo->out, 0, 0, *bo, nullptr);
+        if (ownBytes)
+            hipLaunchKernelGGL((k_stuff_bytes<true, true>), dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
+                               ws.ffCount, groupSum, ws.result, bo->out, 0, 0, *bo, nullptr);
+        else
+            hipLaunchKernelGGL((k_stuff_bytes<true, false>), dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
+                               ws.ffCount, groupSum, ws.result, bo->out, 0, 0, *bo, nullptr);
     } else {
         BatchOutput none = {};
-        hipLaunchKernelGGL(k_stuff_bytes<false>, dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
-                           ws.ffCount, groupSum, ws.result, d_out, prefixLen, outCapacity, none, ws.hostResult);
+        if (ownBytes)
+            hipLaunchKernelGGL((k_stuff_bytes<false, true>), dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
+                               ws.ffCount, groupSum, ws.result, d_out, prefixLen, outCapacity, none, ws.hostResult);
+        else
+            hipLaunchKernelGGL((k_stuff_bytes<false, false>), dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
+                               ws.ffCount, groupSum, ws.result, d_out, prefixLen, outCapacity, none, ws.hostResult);
     }
     return hipGetLastError();
 }
