@@ -102,3 +102,24 @@ def test_noise_q100_full_size(sname):
     assert (info.width, info.height, info.restart_interval) == (w, h, lay.mcus_per_row)
     assert np.array_equal(ctx.decoded_coefficients(info), held)
     ctx.close()
+
+
+@pytest.mark.parametrize("blocks", [140000, 160000, 240000, 260000, 490000, 510000])
+def test_sizes_on_either_side_of_the_kernel_thresholds(blocks):
+    """Images just below and just above the sizes at which the library changes kernels (bit writer
+    on groups from 150 k blocks, histogram pass on groups from 250 k, deferred placement from
+    500 k), with their real sizes and no diagnostic switch: whole files against the CPU checker."""
+    import oracle as O
+    w = 2560
+    mcus = -(-blocks // 6)                     # 4:2:0: six blocks per MCU
+    h = -(-mcus // (w // 16)) * 16 - 5         # ragged last MCU row
+    img = synth.generate("natural", w, h, seed=blocks % 97)
+    qt = T.quality_tables(90)
+    ctx = B.Context(0)
+    try:
+        for ri in (0, w // 16):
+            prm = B.make_params(w, h, T.SCHEME_420, qt, restart_interval=ri)
+            assert abs(int(B.compute_layout(prm).total_blocks) - blocks) < 2000
+            assert ctx.encode_host(img, prm) == O.encode(img, T.SCHEME_420, qt, restart_interval=ri).jpeg, (blocks, ri)
+    finally:
+        ctx.close()
