@@ -560,6 +560,41 @@ struct EmitVisitor {
     }
 };
 
+// The same into a stage in LDS, without an accumulator: every token is ORed into the (zeroed)
+// stage where it belongs, two words at a time.  No branch per token (when a lane's pending word
+// fills up differs from lane to lane, so the flush above is paid at nearly every token of a dense
+// block), half the instructions per token.  `pos` counts bits from bit 31 of stage word 0.
+struct StageVisitor {
+    const u32* dcTab;
+    const u32* acTab;
+    u32* stage;
+    u32 pos;
+    __device__ __forceinline__ void put(u32 bits, u32 len) {   // len <= 27, bits == 0 when len == 0
+        const u32 sh = pos & 31u;
+        const u64 v = (u64)bits << ((64u - sh - len) & 63u);
+        u32* w = stage + (pos >> 5);
+        atomicOr(w, (u32)(v >> 32));
+        atomicOr(w + 1, (u32)v);
+        pos += len;
+    }
+    __device__ __forceinline__ void dc(int cat, u32 amp) {
+        const u32 e = dcTab[cat];
+        put(((e & 0xffffu) << cat) | amp, (e >> 16) + (u32)cat);
+    }
+    __device__ __forceinline__ void ac(int sym, int cat, u32 amp) {
+        const u32 e = acTab[sym];
+        put(((e & 0xffffu) << cat) | amp, (e >> 16) + (u32)cat);
+    }
+    __device__ __forceinline__ void zrl(int cnt) {
+        const u32 e = acTab[0xF0];
+        for (int i = 0; i < cnt; ++i) put(e & 0xffffu, e >> 16);
+    }
+    __device__ __forceinline__ void eob() {
+        const u32 e = acTab[0];
+        put(e & 0xffffu, e >> 16);
+    }
+};
+
 // ---- single-pass bit writer --------------------------------------------------------------
 // Bit lengths, stream positions and the bit writer in one pass over the coefficients.  A
 // tile is 256 consecutive blocks of one image.  The stream position after a block is a
@@ -886,7 +921,7 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
     __syncthreads();
     const u64 wordBase = span[0] >> 5;
     const u64 nWords = ((span[1] + 31) >> 5) - wordBase;
-    const bool staged = nWords <= (u64)kStageWords;
+    const bool staged = nWords < (u64)kStageWords;   // (a token's second word may be the one behind the last)
     if (staged) {
         for (u32 i = threadIdx.x; i < (u32)nWords; i += kEntThreads) stage[i] = 0;
         __syncthreads();
@@ -905,6 +940,10 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
 #pragma unroll
             for (int k = 0; k < kPrivWords; ++k)
                 if ((u32)(32 * k) < bits) out.or32(start + 32 * k, mine32[k]);
+        } else if (staged) {
+            const int t = c == 0 ? 0 : 1;
+            StageVisitor vis{tab + 256 * t, tab + 512 + 256 * t, stage, (u32)(start - (wordBase << 5))};
+            walk_block(w, pred, vis);
         } else {
             const int t = c == 0 ? 0 : 1;
             EmitVisitor<kPrivate> vis{tab + 256 * t, tab + 512 + 256 * t, out, (long long)(start >> 5), 0, (int)(start & 31), true};
