@@ -441,21 +441,20 @@ constexpr int kEmitStageShort = 2048;   // stage words of a tile of short blocks
 constexpr int kEmitStageLong = 6144;    // ... of long blocks (up to 96 bytes per block on average)
 
 // Where a lane's bits go: the LDS stage (native order) or the global stream (swapped).
-template <bool kCount>
-struct BitTargetT {
+struct BitTarget {
     u32* words;
     long long bias;   // index of the stream word that words[0] stands for
     bool swap;
     u32* ff;          // per-chunk 0xFF counts to keep up to date when the target is the stream itself, or null
     __device__ __forceinline__ void or_word(long long index, u32 v) const {
         if (v == 0) return;
-        if (kCount && swap && ff != nullptr) or_counted(words, (u64)index, __builtin_bswap32(v), ff);
+        if (swap && ff != nullptr) or_counted(words, (u64)index, __builtin_bswap32(v), ff);
         else atomicOr(&words[index - bias], swap ? __builtin_bswap32(v) : v);
     }
     // A whole word of the stream that belongs to the caller alone.
     __device__ __forceinline__ void store_word(long long index, u32 v) const {
         words[index - bias] = swap ? __builtin_bswap32(v) : v;
-        if (kCount && swap && ff != nullptr) {
+        if (swap && ff != nullptr) {
             const u32 n = (u32)__popc(ff_bits(v));
             if (n != 0) atomicAdd(&ff[(u64)index >> kChunkWordShift], n);
         }
@@ -513,11 +512,10 @@ struct PrivateVisitor {
 };
 
 // Second walk, for the blocks that did not fit their private words: straight to the target.
-template <bool kCount>
 struct EmitVisitor {
     const u32* dcTab;
     const u32* acTab;
-    BitTargetT<kCount> out;
+    BitTarget out;
     long long word;   // index of the word being filled
     u64 acc;          // pending bits, right aligned
     int n;            // number of pending bits (< 32 between calls)
@@ -761,10 +759,8 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
                                                              u32* __restrict__ words, u64* __restrict__ hostResult,
                                                              long long zeroedBytes, u32* __restrict__ ffCount) {
     // ffCount (may be null): per-chunk counts of the stream's 0xFF bytes (zero at the start), kept up
-    // to date as the words are written, so that no counting pass has to read the stream again.  It
-    // pays for short blocks (1080p: entropy stage 39 -> 34 us); for long ones the counting costs
-    // this kernel more instructions than the pass of its own takes (8192 x 8192 noise 4:4:4: + 95 us
-    // against the pass's 44), so they are launched without.
+    // to date as the words are written, so that no counting pass has to read the stream again
+    // (1080p: entropy stage 39 -> 34 us; 8192 x 8192 noise 4:4:4: 0.508 -> 0.491 ms).
     __shared__ u32 tab[4 * 256];
     constexpr int kStageWords = kPrivate ? kEmitStageShort : kEmitStageLong;
     __shared__ u32 stage[kStageWords];
@@ -927,11 +923,11 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
         __syncthreads();
     }
     if (active) {
-        const BitTargetT<kPrivate> out{staged ? stage : words, staged ? (long long)wordBase : 0, !staged, ffCount};
+        const BitTarget out{staged ? stage : words, staged ? (long long)wordBase : 0, !staged, ffCount};
         const u64 start = pos + (leadMarker ? 16 : 0);   // first bit of the block itself
         if (leadMarker) {
             out.or32(pos, leadMarker << 16);
-            if (kPrivate && ffCount != nullptr) atomicAdd(&ffCount[pos >> 15], kChunkMarkerDelta);   // the marker's 0xFF is no data (bit position -> 4 KiB chunk)
+            if (ffCount != nullptr) atomicAdd(&ffCount[pos >> 15], kChunkMarkerDelta);   // the marker's 0xFF is no data (bit position -> 4 KiB chunk)
         }
         if (bits == 0) {
             // a block with a symbol that has no code: flagged above
@@ -946,19 +942,19 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
             walk_block(w, pred, vis);
         } else {
             const int t = c == 0 ? 0 : 1;
-            EmitVisitor<kPrivate> vis{tab + 256 * t, tab + 512 + 256 * t, out, (long long)(start >> 5), 0, (int)(start & 31), true};
+            EmitVisitor vis{tab + 256 * t, tab + 512 + 256 * t, out, (long long)(start >> 5), 0, (int)(start & 31), true};
             walk_block(w, pred, vis);
             vis.finish();
         }
         if (padBits != 0 && g.padOnes) out.or32(start + bits, ((1u << padBits) - 1u) << (32 - padBits));
         if (tailEoi) {
             out.or32(start + bits + padBits, 0xffd9u << 16);
-            if (kPrivate && ffCount != nullptr) atomicAdd(&ffCount[(start + bits + padBits) >> 15], kChunkMarkerDelta);
+            if (ffCount != nullptr) atomicAdd(&ffCount[(start + bits + padBits) >> 15], kChunkMarkerDelta);
         }
     }
     if (staged) {
         __syncthreads();
-        if (kPrivate && ffCount != nullptr) {
+        if (ffCount != nullptr) {
             copy_out_counted(stage, (u32)nWords, wordBase, words, ffCount);
         } else {
             for (u32 i = threadIdx.x; i < (u32)nWords; i += kEntThreads) {
@@ -1401,10 +1397,10 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     // word of the stream exactly once, with plain stores.)
     const bool deferred = !fromRecords && groups && ws.tileSlots != nullptr && ws.groupTile == kGrpTileBlocks;
     const long long clear16 = deferred ? 0 : zero / 16;
-    // Who keeps the per-chunk counts of 0xFF bytes: the kernels that write the stream (deferred
-    // placement, the one-lane-per-block writer), or a pass of its own behind them.
+    // Who keeps the per-chunk counts of 0xFF bytes: the kernels that write the stream, or (for the
+    // writer on symbol records) a pass of its own behind them.
     const bool shortBlocks = ws.avgBlockBits <= 128;   // long blocks (noise, q=100) do not fit the private words; unknown lengths count as short
-    const bool counted = deferred || (!fromRecords && (groups || shortBlocks));
+    const bool counted = !fromRecords;
     long long prepGrid = (clear16 > tileCount / 2 ? clear16 : tileCount / 2) / (256 * 4);
     prepGrid = prepGrid < 1 ? 1 : (prepGrid > 2048 ? 2048 : prepGrid);
     // Chunks the stream can have at most: from the bound that was cleared.
@@ -1449,7 +1445,7 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     else
         hipLaunchKernelGGL(k_encode_bits<false>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
                            ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult, zero,
-                           nullptr);
+                           ws.ffCount);
     // As many workgroups as the device holds at once (five per CU): a workgroup's run of chunks is
     // one chain (a chunk's bytes are asked for while the chunk in front is worked on), a second
     // round of workgroups would start that chain all over.  (Diagnostic switch JPEGENC_STUFF_GRID.)
