@@ -711,7 +711,8 @@ ImagePtr ImageLoader::LoadPNG(std::string path, SamplingDefinition scheme) {
     const bool depthOk = colour == 0   ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
                          : colour == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8)
                                        : (depth == 8 || depth == 16);
-    if (width == 0 || height == 0 || channels == 0 || !depthOk || interlace > 1) {
+    // (JPEG takes 65535 x 65535 at most: larger headers are refused before anything is sized by them.)
+    if (width == 0 || height == 0 || width > 65535 || height > 65535 || channels == 0 || !depthOk || interlace > 1) {
         std::cout << "Failed to decode png " << path << ": unsupported format" << std::endl;
         return nullptr;
     }

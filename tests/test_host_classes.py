@@ -134,6 +134,44 @@ def test_png_reader_takes_every_colour_type_and_depth(tmp_path, interlace):
             assert np.array_equal(got, want), (colour, depth, w, h, interlace)
 
 
+def test_png_reader_refuses_damaged_and_oversized_files(tmp_path):
+    # The reference prints lodepng's error and returns no image (ImageLoader.cpp:184-188); here the same outcome
+    # (exit status 1, no output file) for cut files, sizes JPEG cannot hold and depths the colour type lacks.
+    # An index past the end of the palette is not an error: it reads as black (lodepng's getPixelColorRGBA8).
+    import struct
+    import zlib
+    exe = os.path.join(LIB, "host_selftest")
+    rng = np.random.RandomState(4)
+
+    def refused(blob):
+        src, dst = tmp_path / "bad.png", tmp_path / "bad.ppm"
+        src.write_bytes(blob)
+        if dst.exists():
+            dst.unlink()
+        r = subprocess.run([exe, "convert", str(src), str(dst)], capture_output=True, text=True)
+        return r.returncode == 1 and not dst.exists()
+
+    good = _png_bytes(rng.randint(0, 256, (9, 14, 3)), 2, 8, True)
+    for cut in (8, 20, 40, len(good) // 2, len(good) - 20):
+        assert refused(good[:cut]), cut
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xffffffff)
+
+    for w, h in ((0x7fffffff, 0x7fffffff), (65536, 1), (1, 65536), (0, 4)):
+        blob = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(b"\0" * 16)) + chunk(b"IEND", b""))
+        assert refused(blob), (w, h)
+    # depth the colour type does not allow (truecolour of 4 bits)
+    blob = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 2, 2, 4, 2, 0, 0, 0))
+            + chunk(b"IDAT", zlib.compress(b"\0" * 16)) + chunk(b"IEND", b""))
+    assert refused(blob)
+    src, dst = tmp_path / "pal.png", tmp_path / "pal.ppm"
+    src.write_bytes(_png_bytes(np.array([[[0], [1], [3]]]), 3, 2, False, [[10, 20, 30], [40, 50, 60]]))
+    subprocess.check_call([exe, "convert", str(src), str(dst)])
+    assert dst.read_text().split()[4:] == ["10", "20", "30", "40", "50", "60", "0", "0", "0"]
+
+
 def test_bitbuffer_escaping_and_padding():
     r = _selftest()
     # 16 one-bits escaped (two stuffed zeros), then 9 plain bits 1010 0101 1, zero padded
