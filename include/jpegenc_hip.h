@@ -275,7 +275,10 @@ int jpeg_hip_emit_scan_host(jpeg_hip_ctx* ctx, uint8_t* h_out, int64_t out_capac
  * order (Encoder::createBlocks), 64 zig-zag ordered int16 per block -- the values
  * Encoder::calculateDCValues/ACValues read (Encoder.cpp:268-269, 308-309). */
 int jpeg_hip_get_coefficients(jpeg_hip_ctx* ctx, int channel, int16_t* h_out, int64_t capacity_values);
-/* Device pointer of the scan-ordered coefficient buffer (int16, total_blocks * 64). */
+/* Device pointer of the coefficients in scan order (int16, total_blocks * 64: a block's 64 zig-zag
+ * ordered values are contiguous).  For large images the library keeps the two halves of the
+ * blocks in two planes: the pointer is then that of a joined copy made by this call (valid
+ * until the context's next transform or call of this function); null when that copy fails. */
 const int16_t* jpeg_hip_coefficients_device(jpeg_hip_ctx* ctx);
 
 /* ---- sharded images (one band per GPU) ---------------------------------------------- */

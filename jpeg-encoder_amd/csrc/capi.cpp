@@ -179,6 +179,19 @@ void fill_kgeom(jpeg_hip_ctx* ctx) {
     k.tableStride = 1024;
     k.nGains = 0;
     k.groupMask = (const unsigned char*)ctx->gmask.p;
+    // Large images keep groups 0..3 of all blocks in the first half of the coefficient buffer
+    // and groups 4..7 in the second: the histogram pass and the bit writer read non-empty groups
+    // only, memory comes in lines of 128 bytes, and the second half of most blocks of a
+    // photographic image is empty (16384 x 16384 4:2:0 q=90: 29 % of the blocks have anything
+    // there), so whole lines of the second plane are never fetched: 857 -> 607 MB per pass, histogram
+    // pass 183 -> 157 us.  Smaller images (3840 x 2160 4:4:4, 292 k blocks: 23.5 -> 24.5 us) and
+    // batches keep a block's 128 bytes together.  (Diagnostic switch JPEGENC_SPLIT_MIN_BLOCKS, read
+    // at every call so that a test can set it.)
+    const char* splitEnv = getenv("JPEGENC_SPLIT_MIN_BLOCKS");
+    // (The kernels keep the distance between the planes in 32 bits.)
+    const bool split = g.totalBlocks >= (splitEnv ? atoll(splitEnv) : 400000) && g.totalBlocks < (1ll << 25);
+    k.coefPitch = split ? 64 : 128;
+    k.coefHigh = split ? (long long)g.totalBlocks * 64 : 64;
 }
 
 // Workspace for `images` images of the current geometry (1 outside batch mode; in a batch
@@ -589,7 +602,7 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->gmask, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->groupSum, &ctx->result,
                       &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart,
                       &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum, &ctx->pixelsF, &ctx->pipeIn[0], &ctx->pipeIn[1],
-                      &ctx->pipeOut, &ctx->histDone, &ctx->gather, &ctx->repacked, &ctx->records, &ctx->recCount, &ctx->tileSlots};
+                      &ctx->pipeOut, &ctx->histDone, &ctx->gather, &ctx->joined, &ctx->repacked, &ctx->records, &ctx->recCount, &ctx->tileSlots};
     delete ctx->decoded;
     delete ctx->workers;
     delete ctx->packers;
@@ -972,20 +985,28 @@ int jpeg_hip_get_coefficients(jpeg_hip_ctx* ctx, int channel, int16_t* h_out, in
     const Geometry& g = ctx->geo;
     const int64_t perMcu = g.chanBlocks[channel];
     if (capacity_values < g.nMcu * perMcu * 64) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "coefficient buffer too small");
-    // Scan order interleaves the channels per MCU: this channel's slices are gathered on the
+    // Scan order interleaves the channels per MCU: this channel's blocks are gathered on the
     // device and leave in one piece (a strided copy to pageable memory goes row by row).
     const size_t bytes = (size_t)g.nMcu * perMcu * 128;
     HIP_TRY(ctx, ctx->gather.ensure(bytes));
-    HIP_TRY(ctx, hipMemcpy2DAsync(ctx->gather.p, (size_t)perMcu * 128, (const char*)ctx->coef.p + (size_t)g.chanOffset[channel] * 128,
-                                  (size_t)g.blocksPerMcu * 128, (size_t)perMcu * 128, (size_t)g.nMcu,
-                                  hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, launch_gather_blocks(ctx->kg, (const int16_t*)ctx->coef.p, g.chanOffset[channel], (int)perMcu, ctx->gather.p, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(h_out, ctx->gather.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, wait_stream(ctx));
     return JPEG_HIP_OK;
 }
 
 const int16_t* jpeg_hip_coefficients_device(jpeg_hip_ctx* ctx) {
-    return ctx && ctx->transformed ? (const int16_t*)ctx->coef.p : nullptr;
+    if (!ctx || !ctx->transformed) return nullptr;
+    if (ctx->kg.coefPitch == 128) return (const int16_t*)ctx->coef.p;
+    // The two halves of the blocks lie apart (fill_kgeom): the caller gets a joined copy.
+    DeviceScope deviceScope((ctx)->device);
+    if (deviceScope.err != hipSuccess) return nullptr;
+    const size_t bytes = (size_t)ctx->geo.totalBlocks * 128;
+    if (ctx->joined.ensure(bytes) != hipSuccess ||
+        launch_gather_blocks(ctx->kg, (const int16_t*)ctx->coef.p, 0, ctx->geo.blocksPerMcu, ctx->joined.p, ctx->stream) != hipSuccess ||
+        wait_stream(ctx) != hipSuccess)
+        return nullptr;
+    return (const int16_t*)ctx->joined.p;
 }
 
 int jpeg_hip_analyze_band(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
@@ -1151,6 +1172,8 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     k.batch = n;
     k.nMcu = g.nMcu * n;
     k.totalBlocks = g.totalBlocks * n;
+    k.coefPitch = 128;   // a pass is transformed, counted and written in parts, each in its own slice of the buffer
+    k.coefHigh = 64;
     // Frames whose rows do not start on 4-byte boundaries are realigned first (see do_transform).
     if (ctx->fmt == JPEG_HIP_RGB8 && ((ctx->stride & 3) != 0 || (imageStride & 3) != 0 || ((uintptr_t)d_rgb & 3) != 0)) {
         int64_t dstStride = 0;

@@ -224,6 +224,7 @@ struct jpeg_hip_ctx {
     jpeghip::WorkerPool* packers = nullptr;               // pack host pixels into pinned memory (uploads, jpeg_hip_encode_batch_host)
     jpeghip::HostBuf uploadStage[2];                      // pinned blocks jpeg_hip_upload_pixels sends its pieces from
     hipEvent_t uploadEvent[2] = {nullptr, nullptr};
+    jpeghip::DevBuf joined;                               // all blocks with their halves joined (jpeg_hip_coefficients_device)
     jpeghip::DevBuf gather;                               // one channel's coefficients, contiguous (jpeg_hip_get_coefficients)
     jpeghip::DevBuf tileSlots;                            // staged bits of the bit writer's tiles (EntropyWorkspace::tileSlots)
     jpeghip::DevBuf records, recCount;                    // symbol records of the current coefficients (launch_symbol_records)

@@ -110,16 +110,24 @@ __device__ __forceinline__ void walk_block(const u32 (&w)[32], int pred, Visitor
     if (last != 63) vis.eob();
 }
 
-__device__ __forceinline__ void load_block(const int16_t* coef, long long b, u32 (&w)[32]) {
-    const uint4* src = (const uint4*)(coef + b * 64);
+// A block's 64 coefficients: groups 0..3 and groups 4..7 from where the geometry says they lie
+// (KGeom::coefPitch, KGeom::coefHigh).
+__device__ __forceinline__ void load_block(const KGeom& g, const int16_t* coef, long long b, u32 (&w)[32]) {
+    const uint4* low = (const uint4*)((const char*)coef + b * g.coefPitch);
+    const uint4* high = (const uint4*)((const char*)low + g.coefHigh);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const uint4 t = src[i];
+        const uint4 t = i < 4 ? low[i] : high[i - 4];
         w[4 * i] = t.x;
         w[4 * i + 1] = t.y;
         w[4 * i + 2] = t.z;
         w[4 * i + 3] = t.w;
     }
+}
+
+// DC term of block b.
+__device__ __forceinline__ int load_dc(const KGeom& g, const int16_t* coef, long long b) {
+    return *(const int16_t*)((const char*)coef + b * g.coefPitch);
 }
 
 constexpr int kEntThreads = 256;
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(kEntThreads) void k_histogram(KGeom g, const int16_
     __shared__ u32 lh[4 * 256];   // DC-Y, DC-C, AC-Y, AC-C (Encoder.cpp:368-416)
     for (int i = threadIdx.x; i < 1024; i += kEntThreads) lh[i] = 0;
     __syncthreads();
-    const int16_t* image = coef + (long long)blockIdx.y * g.blocksPerImage * 64;
+    const long long image = (long long)blockIdx.y * g.blocksPerImage;   // first block of this image
     const u32 blocks = (u32)g.blocksPerImage;
     const u32 stride = gridDim.x * kEntThreads;
     for (u32 bl = blockIdx.x * kEntThreads + threadIdx.x; __any(bl < blocks); bl += stride) {
@@ -194,8 +202,8 @@ __global__ __launch_bounds__(kEntThreads) void k_histogram(KGeom g, const int16_
         const u32 cur = active ? bl : blocks - 1;   // lanes past the end stay in step for the shuffle
         const BlockRole role = block_role(g, cur);
         u32 w[32];
-        load_block(image, cur, w);
-        const int fetched = image[dc_predictor_source(role, cur) * 64];
+        load_block(g, coef, image + cur, w);
+        const int fetched = load_dc(g, coef, image + dc_predictor_source(role, cur));
         const int pred = dc_predictor_lanes(role, coef_at(w, 0), fetched, active);
         if (active) {
             const int t = role.c == 0 ? 0 : 1;
@@ -788,8 +796,8 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
     u32 w[32];
     int fetchedDc = 0;
     if (active) {   // in flight while the tables are staged
-        load_block(coef, b, w);
-        fetchedDc = coef[dc_predictor_source(role, b) * 64];
+        load_block(g, coef, b, w);
+        fetchedDc = load_dc(g, coef, dc_predictor_source(role, b));
     }
     const u32* myTables = tables + image * g.tableStride;
     // A symbol the tables have no code for (length 0) gets a length no block can reach, so

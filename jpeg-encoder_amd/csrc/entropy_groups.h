@@ -82,6 +82,8 @@ __device__ __forceinline__ u32 wave_scan_add(u32 v) {
 // One wave's view of its tile.
 struct GroupTile {
     const char* base;        // address of the tile's first block minus kGrpBaseBlocks blocks: predictors lie in front
+    u32 shift;               // log2 of the bytes from one block's groups 0..3 to the next block's: 7 or 6 (KGeom::coefPitch)
+    u32 high;                // bytes from a block's groups 0..3 to its groups 4..7 (KGeom::coefHigh)
     const unsigned char* mask;   // group masks of the tile's blocks
     u32 first;               // first block of the tile inside its image
     int nBlocks;
@@ -170,8 +172,8 @@ __device__ __forceinline__ void group_issue_loads(const GroupTile& t, int firstI
     const u32 lb = item >> 4, grp = item & 7u;
     const u32 role = t.role[lb];
     const u32 back = (role & 2u) ? 0u : ((role >> 2) & 31u);
-    ld.d = *(const uint4*)(t.base + ((lb + kGrpBaseBlocks) * 128u + grp * 16u));
-    ld.pred = *(const unsigned short*)(t.base + (lb + kGrpBaseBlocks - back) * 128u);
+    ld.d = *(const uint4*)(t.base + (((lb + kGrpBaseBlocks) << t.shift) + (grp & 3u) * 16u + (grp >= 4u ? t.high : 0u)));
+    ld.pred = *(const unsigned short*)(t.base + ((lb + kGrpBaseBlocks - back) << t.shift));
 }
 
 // What a lane knows about its group before it looks at single coefficients.
@@ -287,7 +289,9 @@ __global__ __launch_bounds__(256) void k_histogram_tiles(KGeom g, const int16_t*
         t.first = tile * kHistTileBlocks;
         const u32 left = (u32)g.blocksPerImage - t.first;
         t.nBlocks = (int)(left < (u32)kHistTileBlocks ? left : (u32)kHistTileBlocks);
-        t.base = (const char*)(coef + ((long long)image * g.blocksPerImage + t.first) * 64) - (long long)kGrpBaseBlocks * 128;
+        t.shift = g.coefPitch == 64 ? 6u : 7u;
+        t.high = (u32)g.coefHigh;
+        t.base = (const char*)coef + (((long long)image * g.blocksPerImage + t.first - (long long)kGrpBaseBlocks) << t.shift);
         t.mask = g.groupMask + (long long)image * g.blocksPerImage + t.first;
         t.nItems = 0;
         t.tooMany = false;
@@ -601,7 +605,9 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
         const long long left = g.blocksPerImage - (long long)t.first;
         t.nBlocks = (int)(left < tileBlocks ? left : tileBlocks);
     }
-    t.base = (const char*)(coef + ((long long)image * g.blocksPerImage + t.first) * 64) - (long long)kGrpBaseBlocks * 128;
+    t.shift = g.coefPitch == 64 ? 6u : 7u;
+    t.high = (u32)g.coefHigh;
+    t.base = (const char*)coef + (((long long)image * g.blocksPerImage + t.first - (long long)kGrpBaseBlocks) << t.shift);
     t.mask = g.groupMask + (long long)image * g.blocksPerImage + t.first;
     t.nItems = 0;
     t.tooMany = false;

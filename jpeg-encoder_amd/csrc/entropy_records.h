@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void k_symbol_records(KGeom g, const int16_t* 
             const long long left = g.blocksPerImage - (long long)t.first;
             t.nBlocks = (int)(left < kGrpTileBlocks ? left : kGrpTileBlocks);
         }
-        t.base = (const char*)(coef + (long long)t.first * 64) - (long long)kGrpBaseBlocks * 128;
+        t.shift = g.coefPitch == 64 ? 6u : 7u;
+        t.high = (u32)g.coefHigh;
+        t.base = (const char*)coef + (((long long)t.first - (long long)kGrpBaseBlocks) << t.shift);
         t.mask = g.groupMask + t.first;
         t.nItems = 0;
         t.tooMany = false;

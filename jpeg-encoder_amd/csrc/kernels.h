@@ -39,6 +39,13 @@ struct KGeom {
     // One byte per block of the band (or batch), written by the transform: bit k is set when the
     // block's k-th group of eight zig-zag ordered coefficients is not all zero.
     const unsigned char* groupMask;
+    // Where a block's coefficients lie.  Groups 0..3 of block b start coefPitch * b bytes into the
+    // buffer, its groups 4..7 coefHigh bytes behind them: 128 and 64 when a block's 128 bytes
+    // are contiguous; 64 and half the buffer's size when the two halves of all blocks form
+    // two planes (the second half of most blocks of a photographic image is empty and is then
+    // never fetched: memory is read in lines of 128 bytes).  coefHigh stays below 2^31.
+    int coefPitch;
+    long long coefHigh;
     // Encoder::multiplyColorChannelBy calls made after convertToYCbCr, in call order.
     int nGains;
     struct {
@@ -102,6 +109,10 @@ constexpr int kStuffChunk = 4096;   // unstuffed bytes handled by one workgroup 
 // d_gmask receives one byte per block: which of its eight groups of eight coefficients are not all zero.
 hipError_t launch_transform(const KGeom& g, const void* d_rgb, const float* d_qtab, int16_t* d_coef,
                             unsigned char* d_gmask, hipStream_t s, unsigned long long* d_clearHist = nullptr);
+
+// Blocks [firstInMcu, firstInMcu + perMcu) of every MCU of the band to d_out, 128 contiguous bytes per
+// block, from wherever g keeps the blocks' halves.
+hipError_t launch_gather_blocks(const KGeom& g, const int16_t* d_coef, int firstInMcu, int perMcu, void* d_out, hipStream_t s);
 
 // Pixel filter (JPEG_HIP_FILTER_*) over `rows` rows of `width` pixels: src in sampleFormat
 // with srcStride bytes per row, dst float RGB with 3 * width floats per row (may be src).

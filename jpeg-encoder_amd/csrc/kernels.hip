@@ -254,9 +254,12 @@ __global__ __launch_bounds__(kGenThreads) void k_transform_generic(KGeom g, cons
         const int hi = (int)rintf(clamp_coef(v[kZZ[z + 1]] / qc[kZZ[z + 1]]));
         packed[z >> 1] = ((u32)lo & 0xffffu) | ((u32)hi << 16);
     }
-    uint4* dst = (uint4*)(coef + b * 64);
+    uint4* dst = (uint4*)((unsigned char*)coef + b * g.coefPitch);                // groups 0..3
+    uint4* dstHigh = (uint4*)((unsigned char*)coef + b * g.coefPitch + g.coefHigh);   // groups 4..7
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dst[i] = make_uint4(packed[4 * i], packed[4 * i + 1], packed[4 * i + 2], packed[4 * i + 3]);
+    for (int i = 0; i < 4; ++i) dst[i] = make_uint4(packed[4 * i], packed[4 * i + 1], packed[4 * i + 2], packed[4 * i + 3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dstHigh[i] = make_uint4(packed[16 + 4 * i], packed[17 + 4 * i], packed[18 + 4 * i], packed[19 + 4 * i]);
     gmask[b] = (unsigned char)group_mask(packed);
 }
 
@@ -380,27 +383,7 @@ __device__ __forceinline__ void load_row8(const unsigned char* __restrict__ rgb,
     }
 }
 
-// x255, transform, quantize with the reciprocal pairs of channel table `tab`, zig-zag,
-// and store the block's 128 bytes.
-__device__ __forceinline__ void finish_block(float (&v)[64], const float* __restrict__ rhi,
-                                             const float* __restrict__ rlo, int16_t* __restrict__ dstBlock) {
-#pragma unroll
-    for (int i = 0; i < 64; ++i) v[i] = v[i] * 255.0f;   // SIMD256.h:484-494
-    aan2d(v);
-    u32 packed[32];
-#pragma unroll
-    for (int z = 0; z < 64; z += 2) {
-        const int a = kZZ[z], b = kZZ[z + 1];
-        const float qa = __builtin_fmaf(v[a], rhi[a], v[a] * rlo[a]) + ROUND_MAGIC;
-        const float qb = __builtin_fmaf(v[b], rhi[b], v[b] * rlo[b]) + ROUND_MAGIC;
-        packed[z >> 1] = __builtin_amdgcn_perm(__float_as_uint(qb), __float_as_uint(qa), 0x05040100u);
-    }
-    uint4* dst = (uint4*)dstBlock;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dst[i] = make_uint4(packed[4 * i], packed[4 * i + 1], packed[4 * i + 2], packed[4 * i + 3]);
-}
-
-// Same as finish_block for row-pair values (see aan2d_pairs), and the wave's 64 blocks go through LDS so that every store
+// x255, transform, quantize, zig-zag on row-pair values (see aan2d_pairs); the wave's 64 blocks go through LDS so that every store
 // instruction writes whole 128-byte lines (8 lanes per block) instead of 64 scattered
 // 16-byte pieces.  `stage` is this wave's area of kRounds-th of 64 x 144 bytes (the 16
 // bytes of padding per block keep the 16-byte LDS accesses conflict free); with kRounds
@@ -409,12 +392,25 @@ __device__ __forceinline__ void finish_block(float (&v)[64], const float* __rest
 // lanes at or beyond `count` hold no block.
 constexpr int kStagePitch = 144;
 
+// Where a wave's blocks go: the address of the first block's groups 0..3, the distance to the
+// next block's, and the distance from a block's groups 0..3 to its groups 4..7 (KGeom::coefPitch,
+// KGeom::coefHigh).
+struct CoefDst {
+    unsigned char* p;
+    u32 pitch;
+    long long high;
+};
+__device__ __forceinline__ CoefDst coef_dst(const KGeom& g, int16_t* __restrict__ coef, long long block) {
+    return CoefDst{(unsigned char*)coef + block * g.coefPitch, (u32)g.coefPitch, g.coefHigh};
+}
+
 template <int kRounds, bool kClamp = false>
 __device__ __forceinline__ void finish_block_staged(f2 (&a)[32], const float* __restrict__ rhi,
                                                     const float* __restrict__ rlo, unsigned char* stage,
-                                                    int16_t* __restrict__ waveBase, unsigned char* __restrict__ waveMask,
+                                                    CoefDst waveBase, unsigned char* __restrict__ waveMask,
                                                     int blockStride, int count) {
     const int lane = threadIdx.x & 63;
+    const long long laneOff = (lane & 3) * 16 + ((lane & 4) ? waveBase.high : 0ll);   // eight lanes per block, 16 bytes each
     constexpr int kPerRound = 64 / kRounds;
     u32 p[32];
     transform_quantize_pairs<kClamp>(a, rhi, rlo, p);
@@ -435,7 +431,7 @@ __device__ __forceinline__ void finish_block_staged(f2 (&a)[32], const float* __
             const int blk = round * kPerRound + local;
             if (blk < count) {
                 const uint4 t = *(const uint4*)(stage + local * kStagePitch + (lane & 7) * 16);
-                *(uint4*)((unsigned char*)waveBase + (long long)blk * blockStride * 128 + (lane & 7) * 16) = t;
+                *(uint4*)(waveBase.p + (long long)blk * blockStride * waveBase.pitch + laneOff) = t;
             }
         }
         if (kRounds > 1) {
@@ -451,9 +447,10 @@ __device__ __forceinline__ void finish_block_staged(f2 (&a)[32], const float* __
 template <bool kClamp = false>
 __device__ __forceinline__ void finish_block_staged_y(f2 (&a)[32], const float* __restrict__ rhi,
                                                       const float* __restrict__ rlo, unsigned char* stage,
-                                                      int16_t* __restrict__ waveBase, unsigned char* __restrict__ waveMask,
+                                                      CoefDst waveBase, unsigned char* __restrict__ waveMask,
                                                       int mcuCount) {
     const int lane = threadIdx.x & 63;
+    const long long laneOff = (lane & 3) * 16 + ((lane & 4) ? waveBase.high : 0ll);
     u32 p[32];
     transform_quantize_pairs<kClamp>(a, rhi, rlo, p);
     if ((lane >> 2) < mcuCount) waveMask[(lane >> 2) * 6 + (lane & 3)] = (unsigned char)group_mask(p);
@@ -473,7 +470,7 @@ __device__ __forceinline__ void finish_block_staged_y(f2 (&a)[32], const float* 
             const int mcu = blk >> 2;
             if (mcu < mcuCount) {
                 const uint4 t = *(const uint4*)(stage + local * kStagePitch + (lane & 7) * 16);
-                *(uint4*)((unsigned char*)waveBase + ((long long)mcu * 6 + (blk & 3)) * 128 + (lane & 7) * 16) = t;
+                *(uint4*)(waveBase.p + ((long long)mcu * 6 + (blk & 3)) * waveBase.pitch + laneOff) = t;
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -559,7 +556,7 @@ __global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned c
         // (l >> 2) * 6 + (l & 3) blocks from the wave's first; staged stores take a uniform
         // stride, so the four blocks of an MCU are addressed through their MCU.
         const int waveMcus = mcuCount - wave * 16;   // MCUs of this wave that exist (may be <= 0)
-        finish_block_staged_y(a, rhi, rlo, stage + wave * 32 * kStagePitch, coef + (mBase + wave * 16) * 6 * 64,
+        finish_block_staged_y(a, rhi, rlo, stage + wave * 32 * kStagePitch, coef_dst(g, coef, (mBase + wave * 16) * 6),
                               gmask + (mBase + wave * 16) * 6, waveMcus);
     }
     __syncthreads();
@@ -574,7 +571,7 @@ __global__ __launch_bounds__(256) void k_transform_420(KGeom g, const unsigned c
             a[2 * i + 1] = (f2){t.z, t.w};
         }
         finish_block_staged<2>(a, rhi + 64 * (1 + ch), rlo + 64 * (1 + ch), stage + wave * 32 * kStagePitch,
-                               coef + (mBase * 6 + 4 + ch) * 64, gmask + mBase * 6 + 4 + ch, 6, mcuCount);
+                               coef_dst(g, coef, mBase * 6 + 4 + ch), gmask + mBase * 6 + 4 + ch, 6, mcuCount);
     }
 }
 
@@ -672,7 +669,7 @@ __global__ __launch_bounds__(256) void k_transform_420f(KGeom g, const unsigned 
             __builtin_amdgcn_sched_barrier(0);
         }
         const int waveMcus = mcuCount - wave * 16;   // MCUs of this wave that exist (may be <= 0)
-        finish_block_staged_y<true>(a, rhi, rlo, stage + wave * 32 * kStagePitch, coef + (mBase + wave * 16) * 6 * 64,
+        finish_block_staged_y<true>(a, rhi, rlo, stage + wave * 32 * kStagePitch, coef_dst(g, coef, (mBase + wave * 16) * 6),
                                     gmask + (mBase + wave * 16) * 6, waveMcus);
     }
     __syncthreads();
@@ -687,7 +684,7 @@ __global__ __launch_bounds__(256) void k_transform_420f(KGeom g, const unsigned 
             a[2 * i + 1] = (f2){t.z, t.w};
         }
         finish_block_staged<2, true>(a, rhi + 64 * (1 + ch), rlo + 64 * (1 + ch), stage + wave * 32 * kStagePitch,
-                                     coef + (mBase * 6 + 4 + ch) * 64, gmask + mBase * 6 + 4 + ch, 6, mcuCount);
+                                     coef_dst(g, coef, mBase * 6 + 4 + ch), gmask + mBase * 6 + 4 + ch, 6, mcuCount);
     }
 }
 
@@ -741,7 +738,7 @@ __global__ __launch_bounds__(3 * k444Positions) void k_transform_444(KGeom g, co
         }
         __builtin_amdgcn_sched_barrier(0);   // row pair by row pair: bounds the live registers
     }
-    finish_block_staged<2>(a, rhi, rlo, stage + c * 32 * kStagePitch, coef + (m0w * 3 + c) * 64, gmask + m0w * 3 + c, 3, count);
+    finish_block_staged<2>(a, rhi, rlo, stage + c * 32 * kStagePitch, coef_dst(g, coef, m0w * 3 + c), gmask + m0w * 3 + c, 3, count);
 }
 
 // 4:4:4 with the conversion shared between the channels: one wave per workgroup, one lane per
@@ -787,11 +784,26 @@ __global__ __launch_bounds__(64) void k_transform_444_shared(KGeom g, const unsi
         __builtin_amdgcn_sched_barrier(0);   // row pair by row pair: bounds the live registers
     }
     // The three transforms one after the other.
-    finish_block_staged<4>(ay, rhi, rlo, stage, coef + m0w * 3 * 64, gmask + m0w * 3, 3, count);
+    finish_block_staged<4>(ay, rhi, rlo, stage, coef_dst(g, coef, m0w * 3), gmask + m0w * 3, 3, count);
     __builtin_amdgcn_sched_barrier(0);
-    finish_block_staged<4>(acb, rhi + 64, rlo + 64, stage, coef + (m0w * 3 + 1) * 64, gmask + m0w * 3 + 1, 3, count);
+    finish_block_staged<4>(acb, rhi + 64, rlo + 64, stage, coef_dst(g, coef, m0w * 3 + 1), gmask + m0w * 3 + 1, 3, count);
     __builtin_amdgcn_sched_barrier(0);
-    finish_block_staged<4>(acr, rhi + 128, rlo + 128, stage, coef + (m0w * 3 + 2) * 64, gmask + m0w * 3 + 2, 3, count);
+    finish_block_staged<4>(acr, rhi + 128, rlo + 128, stage, coef_dst(g, coef, m0w * 3 + 2), gmask + m0w * 3 + 2, 3, count);
+}
+
+// Blocks [firstInMcu, firstInMcu + perMcu) of every MCU, one after the other with their 128
+// bytes in one piece, wherever the geometry keeps the two halves of a block (one lane per
+// group of eight coefficients).
+__global__ __launch_bounds__(256) void k_gather_blocks(KGeom g, const int16_t* __restrict__ coef, int firstInMcu, int perMcu,
+                                                       long long blocksOut, uint4* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= blocksOut * 8) return;
+    const long long i = idx >> 3;
+    const int grp = (int)(idx & 7);
+    const long long mcu = i / perMcu;
+    const long long src = mcu * g.bpm + firstInMcu + (i - mcu * perMcu);
+    const char* from = (const char*)coef + src * g.coefPitch + (grp & 3) * 16 + ((grp & 4) ? g.coefHigh : 0ll);
+    out[idx] = *(const uint4*)from;
 }
 
 // Pixel filters in front of the transform.  One thread per pixel; in place when src == dst.
@@ -877,6 +889,14 @@ hipError_t launch_interleave_planes(const float* d_planes, long long planeFloats
                                     hipStream_t s) {
     hipLaunchKernelGGL(k_interleave_planes, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, s, d_planes, planeFloats,
                        d_dst, pixels);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_blocks(const KGeom& g, const int16_t* d_coef, int firstInMcu, int perMcu, void* d_out, hipStream_t s) {
+    const long long blocksOut = g.nMcu * perMcu;
+    if (blocksOut <= 0) return hipSuccess;
+    const long long grid = (blocksOut * 8 + 255) / 256;
+    hipLaunchKernelGGL(k_gather_blocks, dim3((unsigned)grid), dim3(256), 0, s, g, d_coef, firstInMcu, perMcu, blocksOut, (uint4*)d_out);
     return hipGetLastError();
 }
 
@@ -1098,7 +1118,7 @@ __global__ __launch_bounds__(64 * kRowsMaxBpm) void k_transform_rows(KGeom g, co
         else gather_block_rows<4>(g, pix, sx0, sy0, hf, nw, nh, interior, c, a);
     }
     finish_block_staged<2, kFloat>(a, qtab + 192 + 64 * c, qtab + 384 + 64 * c, stage + k * 32 * kStagePitch,
-                                   coef + (mBase * g.bpm + k) * 64, gmask + mBase * g.bpm + k, g.bpm, count);
+                                   coef_dst(g, coef, mBase * g.bpm + k), gmask + mBase * g.bpm + k, g.bpm, count);
 }
 
 // The row-wise kernel takes factors 1, 2 and 4 and up to eight blocks per MCU (every scheme

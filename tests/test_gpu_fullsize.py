@@ -104,11 +104,11 @@ def test_noise_q100_full_size(sname):
     ctx.close()
 
 
-@pytest.mark.parametrize("blocks", [140000, 160000, 240000, 260000, 490000, 510000])
+@pytest.mark.parametrize("blocks", [140000, 160000, 240000, 260000, 390000, 410000, 490000, 510000])
 def test_sizes_on_either_side_of_the_kernel_thresholds(blocks):
     """Images just below and just above the sizes at which the library changes kernels (bit writer
-    on groups from 150 k blocks, histogram pass on groups from 250 k, deferred placement from
-    500 k), with their real sizes and no diagnostic switch: whole files against the CPU checker."""
+    on groups from 150 k blocks, histogram pass on groups from 250 k, the two halves of the blocks in
+    two planes from 400 k, deferred placement from 500 k), with their real sizes and no diagnostic switch: whole files against the CPU checker."""
     import oracle as O
     w = 2560
     mcus = -(-blocks // 6)                     # 4:2:0: six blocks per MCU

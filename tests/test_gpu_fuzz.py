@@ -94,6 +94,47 @@ def test_divisors_that_are_not_integers(ctx):
         ctx.begin(B.make_params(16, 16, T.SCHEME_444, bad))
 
 
+@pytest.mark.parametrize("split", ["0", "1000000000"])
+@pytest.mark.parametrize("groups", [False, True])
+def test_both_layouts_of_the_coefficient_buffer(ctx, monkeypatch, split, groups):
+    # The library keeps a block's 128 bytes together, or groups 0..3 of all blocks in one plane and
+    # groups 4..7 in another (large images).  Files, per-channel coefficients and the scan-ordered
+    # device buffer have to be the same either way, with the one-lane-per-block kernels and with
+    # the kernels on groups (switched on for these small images).
+    import ctypes as C
+    monkeypatch.setenv("JPEGENC_SPLIT_MIN_BLOCKS", split)
+    if groups:
+        monkeypatch.setenv("JPEGENC_GROUP_MIN_BLOCKS", "0")
+        monkeypatch.setenv("JPEGENC_HIST_TILES_MIN_BLOCKS", "0")
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rng = np.random.RandomState(5)
+    for (w, h, name, ri, kind, q) in [(640, 480, "420", 0, "natural", 90), (333, 211, "444", 7, "natural", 75),
+                                      (1000, 700, "422", 0, "noise", 100), (97, 61, "411", 3, "natural", 100),
+                                      (1, 1, "420", 0, "natural", 90)]:
+        scheme, qt = T.SCHEMES[name], T.quality_tables(q)
+        img = synth.generate(kind, w, h, seed=int(rng.randint(1, 100)))
+        want = O.encode(img, scheme, qt, restart_interval=ri)
+        prm = B.make_params(w, h, scheme, qt, restart_interval=ri)
+        assert ctx.encode_host(img, prm) == want.jpeg, (w, h, name)
+        lay = B.compute_layout(prm)
+        for c in range(3):
+            assert np.array_equal(ctx.coefficients(c, lay), want.coef[c]), (w, h, name, c)
+        # scan order: the channels' blocks interleaved per MCU
+        total = int(lay.total_blocks)
+        ptr = B.lib().jpeg_hip_coefficients_device(ctx._h)
+        assert ptr
+        got = np.zeros(total * 64, np.int16)
+        assert hip.hipMemcpy(got.ctypes.data, ptr, got.nbytes, 2) == 0   # device to host
+        got = got.reshape(total, 64)
+        n_mcus = int(lay.mcus_per_row) * int(lay.mcu_rows)
+        per = [int(lay.blocks[c]) // n_mcus for c in range(3)]
+        assert sum(per) == int(lay.blocks_per_mcu)
+        want_scan = np.concatenate([np.concatenate([want.coef[c][m * per[c]:(m + 1) * per[c]] for c in range(3)])
+                                    for m in range(n_mcus)])
+        assert np.array_equal(got, want_scan), (w, h, name, "device buffer")
+
+
 def test_mostly_flat_image_with_long_blocks(ctx):
     # Mean block length far below 128 bits (the short-block bit writer is chosen), but a
     # band of noise at q=100 whose blocks overflow the private words and take the second walk.
