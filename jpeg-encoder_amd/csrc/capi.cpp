@@ -144,6 +144,15 @@ int check_pixels(jpeg_hip_ctx* ctx, const void* p, int fmt, int64_t stride) {
 // Real pixel rows reachable from the band's RGB pointer.
 int band_rows_available(const Geometry& g) { return g.height - g.bandRow0 * g.stepH; }
 
+// Chooses where the blocks' halves lie for a buffer of `blocks` blocks (see fill_kgeom).
+void set_coefficient_layout(KGeom& k, int64_t blocks) {
+    const char* splitEnv = getenv("JPEGENC_SPLIT_MIN_BLOCKS");
+    // (The kernels keep the distance between the planes in 32 bits.)
+    const bool split = blocks >= (splitEnv ? atoll(splitEnv) : 400000) && blocks < (1ll << 25);
+    k.coefPitch = split ? 64 : 128;
+    k.coefHigh = split ? (long long)blocks * 64 : 64;
+}
+
 void fill_kgeom(jpeg_hip_ctx* ctx) {
     const Geometry& g = ctx->geo;
     KGeom& k = ctx->kg;
@@ -185,13 +194,9 @@ void fill_kgeom(jpeg_hip_ctx* ctx) {
     // photographic image is empty (16384 x 16384 4:2:0 q=90: 29 % of the blocks have anything
     // there), so whole lines of the second plane are never fetched: 857 -> 607 MB per pass, histogram
     // pass 183 -> 157 us.  Smaller images (3840 x 2160 4:4:4, 292 k blocks: 23.5 -> 24.5 us) and
-    // batches keep a block's 128 bytes together.  (Diagnostic switch JPEGENC_SPLIT_MIN_BLOCKS, read
-    // at every call so that a test can set it.)
-    const char* splitEnv = getenv("JPEGENC_SPLIT_MIN_BLOCKS");
-    // (The kernels keep the distance between the planes in 32 bits.)
-    const bool split = g.totalBlocks >= (splitEnv ? atoll(splitEnv) : 400000) && g.totalBlocks < (1ll << 25);
-    k.coefPitch = split ? 64 : 128;
-    k.coefHigh = split ? (long long)g.totalBlocks * 64 : 64;
+    // small batches keep a block's 128 bytes together.  (Diagnostic switch JPEGENC_SPLIT_MIN_BLOCKS,
+    // read at every call so that a test can set it.)
+    set_coefficient_layout(k, g.totalBlocks);
 }
 
 // Workspace for `images` images of the current geometry (1 outside batch mode; in a batch
@@ -1172,8 +1177,9 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     k.batch = n;
     k.nMcu = g.nMcu * n;
     k.totalBlocks = g.totalBlocks * n;
-    k.coefPitch = 128;   // a pass is transformed, counted and written in parts, each in its own slice of the buffer
-    k.coefHigh = 64;
+    // The planes (if any) span the whole pass; a part of it starts coefPitch bytes per block into
+    // the first plane and finds its second halves the same distance behind.
+    set_coefficient_layout(k, k.totalBlocks);
     // Frames whose rows do not start on 4-byte boundaries are realigned first (see do_transform).
     if (ctx->fmt == JPEG_HIP_RGB8 && ((ctx->stride & 3) != 0 || (imageStride & 3) != 0 || ((uintptr_t)d_rgb & 3) != 0)) {
         int64_t dstStride = 0;
@@ -1222,7 +1228,7 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
             h.k.nMcu = g.nMcu * h.cnt;
             h.k.totalBlocks = g.totalBlocks * h.cnt;
             h.k.groupMask = (const unsigned char*)ctx->gmask.p + (int64_t)h.a * g.totalBlocks;
-            h.coef = (const int16_t*)ctx->coef.p + (int64_t)h.a * g.totalBlocks * 64;
+            h.coef = (const int16_t*)ctx->coef.p + (int64_t)h.a * g.totalBlocks * (k.coefPitch / 2);
             h.tables = (const uint32_t*)ctx->tables.p + (h.k.tableStride ? (size_t)h.a * 1024 : 0);
             h.ws = ctx->ws;
             h.ws.records = nullptr;
@@ -1319,12 +1325,12 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
             HIP_TRY(ctx, hipEventRecord(ctx->groupTime[grp][0], ctx->stream));
         }
         HIP_TRY(ctx, launch_transform(part_geometry(ga, gcnt), d_rgb + (int64_t)ga * imageStride, (const float*)ctx->qtab.p,
-                                      (int16_t*)ctx->coef.p + (int64_t)ga * g.totalBlocks * 64,
+                                      (int16_t*)ctx->coef.p + (int64_t)ga * g.totalBlocks * (k.coefPitch / 2),
                                       (unsigned char*)ctx->gmask.p + (int64_t)ga * g.totalBlocks, ctx->stream));
         if (ctx->profiling) HIP_TRY(ctx, hipEventRecord(ctx->groupTime[grp][1], ctx->stream));
         for (int p = p0; p < p1; ++p) {
             const int a = partBegin[p], cnt = partBegin[p + 1] - a;
-            HIP_TRY(ctx, launch_histogram(part_geometry(a, cnt), (const int16_t*)ctx->coef.p + (int64_t)a * g.totalBlocks * 64,
+            HIP_TRY(ctx, launch_histogram(part_geometry(a, cnt), (const int16_t*)ctx->coef.p + (int64_t)a * g.totalBlocks * (k.coefPitch / 2),
                                           (unsigned long long*)ctx->hist.p + (size_t)a * 1024, ctx->stream, false));
             if (!ctx->partCounted[p]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->partCounted[p], hipEventDisableTiming));
             if (!ctx->partEvent[p]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->partEvent[p], hipEventDisableTiming));
