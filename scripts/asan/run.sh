@@ -23,6 +23,11 @@ for f in a.ppm a.png b.png b_grey.png b_pal.png b_rgba.png c.ppm c.png; do
     timeout -k 10 120 $X/encode_jpeg /tmp/$f /tmp/out.jpg $opt > /dev/null
   done
 done
+# the same with the blocks' halves in two planes (large 4:2:0 images take that layout by themselves)
+for f in a.ppm b.png c.ppm; do
+  JPEGENC_SPLIT_MIN_BLOCKS=0 timeout -k 10 120 $X/encode_jpeg /tmp/$f /tmp/out.jpg 420 90 > /dev/null
+  JPEGENC_SPLIT_MIN_BLOCKS=0 JPEGENC_GROUP_MIN_BLOCKS=0 JPEGENC_HIST_TILES_MIN_BLOCKS=0 timeout -k 10 120 $X/encode_jpeg /tmp/$f /tmp/out.jpg 420 90 restart=8 > /dev/null
+done
 timeout -k 10 120 $X/host_selftest > /dev/null
 timeout -k 10 300 $X/abi_exercise
 echo "asan runs clean"
