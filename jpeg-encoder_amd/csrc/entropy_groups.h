@@ -285,7 +285,9 @@ __global__ __launch_bounds__(256) void k_histogram_tiles(KGeom g, const int16_t*
     t.items = items[wave];
     t.cap = kHistMaxItems;
     t.role = roleTab[wave];
-    for (u32 tile = blockIdx.x * 4u + (u32)wave; tile < tiles; tile += gridDim.x * 4u) {
+    for (u32 turn = blockIdx.x * 4u + (u32)wave; turn < tiles; turn += gridDim.x * 4u) {
+        // From the image's end to its start: what the transform wrote last is still in the memory-side cache.
+        const u32 tile = tiles - 1u - turn;
         t.first = tile * kHistTileBlocks;
         const u32 left = (u32)g.blocksPerImage - t.first;
         t.nBlocks = (int)(left < (u32)kHistTileBlocks ? left : (u32)kHistTileBlocks);
