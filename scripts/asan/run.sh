@@ -1,4 +1,6 @@
 # Runs the ASan driver and selftest over a few inputs and options (GPU box).
+# scripts/asan/out is listed in .gpurunignore (17 MB that no other GPU run reads): take that line out before
+# sending this script to the box.
 set -e
 cd "$(dirname "$0")/../.."
 X=scripts/asan/out
