@@ -164,6 +164,7 @@ struct GroupLoad {
     u32 pred;
 };
 
+template <bool kStream = false>
 __device__ __forceinline__ void group_issue_loads(const GroupTile& t, int firstItem, GroupLoad& ld) {
     const int lane = threadIdx.x & 63;
     int i = firstItem + lane;
@@ -172,7 +173,14 @@ __device__ __forceinline__ void group_issue_loads(const GroupTile& t, int firstI
     const u32 lb = item >> 4, grp = item & 7u;
     const u32 role = t.role[lb];
     const u32 back = (role & 2u) ? 0u : ((role >> 2) & 31u);
-    ld.d = *(const uint4*)(t.base + (((lb + kGrpBaseBlocks) << t.shift) + (grp & 3u) * 16u + (grp >= 4u ? t.high : 0u)));
+    const char* at = t.base + (((lb + kGrpBaseBlocks) << t.shift) + (grp & 3u) * 16u + (grp >= 4u ? t.high : 0u));
+    if (kStream) {   // read once and not again soon: leave the caches to what will be
+        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_nontemporal_load((const u32x4*)at);
+        ld.d = make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+        ld.d = *(const uint4*)at;
+    }
     ld.pred = *(const unsigned short*)(t.base + ((lb + kGrpBaseBlocks - back) << t.shift));
 }
 
@@ -300,13 +308,13 @@ __global__ __launch_bounds__(256) void k_histogram_tiles(KGeom g, const int16_t*
         group_index_tile<false>(g, t);
         u32 carryVal = ~0u;
         GroupLoad ld;
-        group_issue_loads(t, 0, ld);
+        group_issue_loads<true>(t, 0, ld);
         for (int first = 0; first < t.nItems; first += 64) {
             GroupFront f;
             group_front(t, first, ld, carryVal, f);
             const int n = t.nItems - first < 64 ? t.nItems - first : 64;
             carryVal = __builtin_amdgcn_readlane(f.val, n - 1);
-            group_issue_loads(t, first + 64, ld);   // the next chunk's groups arrive while this one is counted
+            group_issue_loads<true>(t, first + 64, ld);   // the next chunk's groups arrive while this one is counted
             u32* ac = mine + f.chroma * (256 * kHistCopies);
             if (f.zr != 0) atomicAdd(&ac[0xF0 * kHistCopies], (u32)f.zr);          // Encoder.cpp:318-328
             if (f.needEob) atomicAdd(&ac[0], 1u);                                  // Encoder.cpp:343-347
@@ -566,7 +574,10 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
     const long long tiles = (long long)tilesPerImage * g.batch;
     // Tile numbers come from a counter: every predecessor of a running tile is running or done
     // (nobody waits for anybody when the placement is deferred).
-    if (threadIdx.x == 0) ticket = kDeferred ? 4ull * blockIdx.x : atomicAdd((unsigned long long*)(state + tiles), 4ull);
+    // Deferred tiles do not depend on each other: they are taken from the band's end, where the memory-side
+    // cache still holds what the transform wrote last (the histogram pass before this one reads with
+    // streaming loads and leaves it there).
+    if (threadIdx.x == 0) ticket = kDeferred ? 4ull * (gridDim.x - 1u - blockIdx.x) : atomicAdd((unsigned long long*)(state + tiles), 4ull);
     for (int i = threadIdx.x; i < 4 * kGrpStageWords; i += 256) (&stage[0][0])[i] = 0;
     __syncthreads();
     const u32 tile = (u32)__builtin_amdgcn_readfirstlane((u32)ticket) + (u32)wave;
@@ -625,13 +636,13 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
     u32 maxTok = 0;
     bool overflow = t.tooMany;
     GroupLoad ld;
-    if (t.nItems > 0) group_issue_loads(t, 0, ld);
+    if (t.nItems > 0) group_issue_loads<kDeferred>(t, 0, ld);
     for (int first = 0; first < t.nItems; first += 64) {
         GroupFront f;
         group_front(t, first, ld, carryVal, f);
         const int n = t.nItems - first < 64 ? t.nItems - first : 64;
         carryVal = __builtin_amdgcn_readlane(f.val, n - 1);
-        group_issue_loads(t, first + 64, ld);   // the next chunk's groups arrive while this one is coded
+        group_issue_loads<kDeferred>(t, first + 64, ld);   // the next chunk's groups arrive while this one is coded
 
         // Tokens of the eight coefficients, with their bit counts.
         typedef short s2 __attribute__((ext_vector_type(2)));
