@@ -392,6 +392,12 @@ __device__ __forceinline__ void load_row8(const unsigned char* __restrict__ rgb,
 // lanes at or beyond `count` hold no block.
 constexpr int kStagePitch = 144;
 
+__device__ __forceinline__ void store_stream(uint4* at, uint4 v) {
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, (u32x4*)at);
+}
+
 // Where a wave's blocks go: the address of the first block's groups 0..3, the distance to the
 // next block's, and the distance from a block's groups 0..3 to its groups 4..7 (KGeom::coefPitch,
 // KGeom::coefHigh).
@@ -399,9 +405,16 @@ struct CoefDst {
     unsigned char* p;
     u32 pitch;
     long long high;
+    bool stream;   // streaming stores, see coef_dst
 };
+template <bool kMayStream = true>
 __device__ __forceinline__ CoefDst coef_dst(const KGeom& g, int16_t* __restrict__ coef, long long block) {
-    return CoefDst{(unsigned char*)coef + block * g.coefPitch, (u32)g.coefPitch, g.coefHigh};
+    // Batch passes store their coefficients with streaming stores: a pass alternates between transform
+    // and histogram launches, and coefficients that wait in the memory-side cache are written back
+    // while the histogram parts read (256 x 1080p: histogram parts 0.362 -> 0.300 ms, transform 0.631
+    // -> 0.638).  For one large image it is a wash (transform + 2.5 us, histogram pass - 3.5 us).
+    // (kMayStream false: kernels of small launches, which do without the test in front of every store.)
+    return CoefDst{(unsigned char*)coef + block * g.coefPitch, (u32)g.coefPitch, g.coefHigh, kMayStream && g.batch > 1};
 }
 
 template <int kRounds, bool kClamp = false>
@@ -431,7 +444,9 @@ __device__ __forceinline__ void finish_block_staged(f2 (&a)[32], const float* __
             const int blk = round * kPerRound + local;
             if (blk < count) {
                 const uint4 t = *(const uint4*)(stage + local * kStagePitch + (lane & 7) * 16);
-                *(uint4*)(waveBase.p + (long long)blk * blockStride * waveBase.pitch + laneOff) = t;
+                uint4* at = (uint4*)(waveBase.p + (long long)blk * blockStride * waveBase.pitch + laneOff);
+                if (waveBase.stream) store_stream(at, t);
+                else *at = t;
             }
         }
         if (kRounds > 1) {
@@ -470,7 +485,9 @@ __device__ __forceinline__ void finish_block_staged_y(f2 (&a)[32], const float* 
             const int mcu = blk >> 2;
             if (mcu < mcuCount) {
                 const uint4 t = *(const uint4*)(stage + local * kStagePitch + (lane & 7) * 16);
-                *(uint4*)(waveBase.p + ((long long)mcu * 6 + (blk & 3)) * waveBase.pitch + laneOff) = t;
+                uint4* at = (uint4*)(waveBase.p + ((long long)mcu * 6 + (blk & 3)) * waveBase.pitch + laneOff);
+                if (waveBase.stream) store_stream(at, t);
+                else *at = t;
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -738,7 +755,7 @@ __global__ __launch_bounds__(3 * k444Positions) void k_transform_444(KGeom g, co
         }
         __builtin_amdgcn_sched_barrier(0);   // row pair by row pair: bounds the live registers
     }
-    finish_block_staged<2>(a, rhi, rlo, stage + c * 32 * kStagePitch, coef_dst(g, coef, m0w * 3 + c), gmask + m0w * 3 + c, 3, count);
+    finish_block_staged<2>(a, rhi, rlo, stage + c * 32 * kStagePitch, coef_dst<false>(g, coef, m0w * 3 + c), gmask + m0w * 3 + c, 3, count);
 }
 
 // 4:4:4 with the conversion shared between the channels: one wave per workgroup, one lane per
@@ -784,11 +801,11 @@ __global__ __launch_bounds__(64) void k_transform_444_shared(KGeom g, const unsi
         __builtin_amdgcn_sched_barrier(0);   // row pair by row pair: bounds the live registers
     }
     // The three transforms one after the other.
-    finish_block_staged<4>(ay, rhi, rlo, stage, coef_dst(g, coef, m0w * 3), gmask + m0w * 3, 3, count);
+    finish_block_staged<4>(ay, rhi, rlo, stage, coef_dst<false>(g, coef, m0w * 3), gmask + m0w * 3, 3, count);
     __builtin_amdgcn_sched_barrier(0);
-    finish_block_staged<4>(acb, rhi + 64, rlo + 64, stage, coef_dst(g, coef, m0w * 3 + 1), gmask + m0w * 3 + 1, 3, count);
+    finish_block_staged<4>(acb, rhi + 64, rlo + 64, stage, coef_dst<false>(g, coef, m0w * 3 + 1), gmask + m0w * 3 + 1, 3, count);
     __builtin_amdgcn_sched_barrier(0);
-    finish_block_staged<4>(acr, rhi + 128, rlo + 128, stage, coef_dst(g, coef, m0w * 3 + 2), gmask + m0w * 3 + 2, 3, count);
+    finish_block_staged<4>(acr, rhi + 128, rlo + 128, stage, coef_dst<false>(g, coef, m0w * 3 + 2), gmask + m0w * 3 + 2, 3, count);
 }
 
 // Blocks [firstInMcu, firstInMcu + perMcu) of every MCU, one after the other with their 128
