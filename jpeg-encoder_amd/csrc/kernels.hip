@@ -457,7 +457,7 @@ __device__ __forceinline__ void finish_block_staged(f2 (&a)[32], const float* __
 }
 
 // Luma variant for the 4:2:0 kernel: lane l holds block (l & 3) of the wave's MCU (l >> 2);
-// an MCU's four luma blocks are contiguous (512 bytes), MCUs are six blocks apart.  Two
+// an MCU's four luma blocks are contiguous (512 bytes, or 256 in each of the two planes), MCUs are six blocks apart.  Two
 // half-wave rounds through a 32-block stage.
 template <bool kClamp = false>
 __device__ __forceinline__ void finish_block_staged_y(f2 (&a)[32], const float* __restrict__ rhi,
