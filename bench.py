@@ -135,8 +135,33 @@ def launch_ranks(n):
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # All ranks are watched: when one dies (before or inside a collective the others would wait
+    # in for ever) or the job runs out of time, the rest are ended -- first asked, then killed.
+    limit = float(os.environ.get("BENCH_RANKS_TIMEOUT", "900"))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    t_end = time.time() + limit
+    timed_out = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs) or time.time() > t_end:
+            timed_out = time.time() > t_end
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.time() + 10.0
+            while any(p.poll() is None for p in procs) and time.time() < t_kill:
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    codes = [p.wait() for p in procs]
+    reader.join(5.0)
+    out = b"".join(c for c in chunks if c)
+    if timed_out:
+        print("bench.py: the ranks did not finish within %.0f s and were ended" % limit, file=sys.stderr)
     sys.stdout.write(out.decode())
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]

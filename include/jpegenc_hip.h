@@ -30,7 +30,8 @@ enum {
     JPEG_HIP_ERR_HIP = -2,              /* a HIP runtime call failed; see jpeg_hip_last_error */
     JPEG_HIP_ERR_BUFFER_TOO_SMALL = -3,
     JPEG_HIP_ERR_BAD_STATE = -4,        /* staged entry points called out of order */
-    JPEG_HIP_ERR_NO_DEVICE = -5
+    JPEG_HIP_ERR_NO_DEVICE = -5,
+    JPEG_HIP_ERR_PEER_FAILED = -6       /* sharded encode: this rank was fine, another rank of the job failed */
 };
 
 /* ReductionMethod, SamplingScheme.h:4-7 */
@@ -113,6 +114,19 @@ const char* jpeg_hip_status_string(int status);
 /* HIP stream the context launches on (a hipStream_t), for callers that time or order work. */
 void* jpeg_hip_stream(jpeg_hip_ctx* ctx);
 
+/* Ordering against the caller's own HIP streams.  The context works on a stream of its own
+ * (jpeg_hip_stream) that does not synchronise with any other, the default stream included, so
+ * a caller that fills a device buffer on its stream and hands the pointer over must say so:
+ * jpeg_hip_wait_for_stream makes everything the context launches from now on wait for the work
+ * queued on hip_stream (a hipStream_t, NULL for the default stream) up to this call;
+ * jpeg_hip_stream_wait_for_ctx is the other direction, for results of entry points that return
+ * before their kernels have finished (jpeg_hip_transform, jpeg_hip_histograms,
+ * jpeg_hip_analyze_band, jpeg_hip_allreduce_histograms, jpeg_hip_finish_band_start).  Neither
+ * blocks the host.  They stand in for the ownership hand-over of Encoder(ImagePtr, ...)
+ * (Encoder.cpp:11-13), which on one CPU thread needs no ordering. */
+int jpeg_hip_wait_for_stream(jpeg_hip_ctx* ctx, void* hip_stream);
+int jpeg_hip_stream_wait_for_ctx(jpeg_hip_ctx* ctx, void* hip_stream);
+
 /* Pure host helper: sizes for a parameter block (no GPU needed). */
 int jpeg_hip_compute_layout(const jpeg_hip_params* params, jpeg_hip_layout* out_layout);
 
@@ -125,18 +139,23 @@ int jpeg_hip_compute_layout(const jpeg_hip_params* params, jpeg_hip_layout* out_
 int jpeg_hip_encode(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
                     const jpeg_hip_params* params, uint8_t* d_out, int64_t out_capacity, int64_t* out_len);
 
-/* jpeg_hip_encode for callers that cannot allocate device memory (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
- * reference.  Same arguments, same bytes written to d_out, but the device workspace
- * (coefficients, histograms, tables, tile states, the unstuffed stream) is a fixed array of
- * jpeg_hip_static_workspace_bytes() bytes (32 MiB) that is part of the library and that every
- * GPU the library runs on holds until the process ends; the call makes no hipMalloc /
- * hipFree.  Limits: 128 bytes per 8x8 block plus the entropy-coded stream of the image must
- * fit the array (1920x1080 in any sampling scheme does); rows of byte pixels that do not
- * start on 4-byte boundaries take a slower kernel instead of a realigned copy.  Larger
- * images fail with JPEG_HIP_ERR_BUFFER_TOO_SMALL and a message.  All calls on one GPU, from
- * any context, share that GPU's array: calls that overlap in time on one GPU race.  The
- * context has to be re-begun (jpeg_hip_begin or a one-call entry point) before staged calls. */
+/* jpeg_hip_encode for callers that cannot allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc, processes whose allocator is owned by someone else).  No
+ * counterpart in the reference.  Same arguments, same bytes written to d_out, but the device
+ * workspace (coefficients, histograms, tables, tile states, the unstuffed stream) is a fixed
+ * array of jpeg_hip_static_workspace_bytes() bytes (32 MiB) that is part of the library and that
+ * every GPU the library runs on holds until the process ends; the call makes no hipMalloc /
+ * hipFree.  Like jpeg_hip_encode it waits for its kernels and reads the result back, so it is
+ * not a call to make while a stream is being captured into a graph.  Limits: 128 bytes per
+ * 8x8 block plus the entropy-coded stream of the image must fit the array (1920x1080 in any
+ * sampling scheme does with per-image tables; with standard_huffman the array has to hold the
+ * worst-case stream of 216 bytes per block instead, which limits it to about 95 000 blocks:
+ * 1920x1080 in 4:2:0 fits, in 4:4:4 it does not); rows of byte pixels that do not start on 4-byte
+ * boundaries take a slower kernel instead of a realigned copy.  Larger images fail with
+ * JPEG_HIP_ERR_BUFFER_TOO_SMALL and a message.  All calls on one GPU, from any context or
+ * thread, share that GPU's array: the library lets one of them in at a time (the others wait
+ * inside the call).  The context has to be re-begun (jpeg_hip_begin or a one-call entry
+ * point) before staged calls. */
 int jpeg_hip_encode_static(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
                            const jpeg_hip_params* params, uint8_t* d_out, int64_t out_capacity, int64_t* out_len);
 int64_t jpeg_hip_static_workspace_bytes(void);
@@ -315,10 +334,26 @@ int jpeg_hip_finish_band_wait(jpeg_hip_ctx* ctx, int64_t* out_len);
  * Encoder.cpp:368-416) and writes its piece of the file; the pieces concatenate in rank order.
  * params->mcu_row_begin / mcu_row_end name this rank's band, restart_interval must be set
  * (bands start on interval boundaries).  Collective: every rank of the communicator has to call
- * it, in the same order as the others. */
+ * it, in the same order as the others.  RCCL is loaded when the first of these entry points
+ * is called (librccl.so.1); without it they return JPEG_HIP_ERR_HIP and the rest of the library
+ * works as before. */
 int jpeg_hip_encode_sharded(jpeg_hip_ctx* ctx, void* rccl_comm, const void* d_rgb_band, int sample_format,
                             int64_t stride_bytes, const jpeg_hip_params* params, uint8_t* d_out, int64_t out_capacity,
                             int64_t* out_len);
+/* Failure handling: every rank takes part in the all-reduce whatever happened to it before
+ * (bad arguments, a refused workspace, a failed launch) -- its histograms then count as empty and a
+ * flag word that travels with them says so -- and when any flag is up no rank writes a piece: the
+ * failing rank returns its own status, every other rank JPEG_HIP_ERR_PEER_FAILED, and the
+ * communicator stays usable.  (The standard tables go through the same exchange, for the flags
+ * alone.)  Only a null context or communicator returns before the collective.  A failure
+ * behind the exchange (an output buffer too small for the piece) is local: the other ranks'
+ * pieces are complete, and a job that wants one verdict calls jpeg_hip_allreduce_status. */
+
+/* One more collective for jobs that want every rank to know whether all pieces were written:
+ * sums a 0/1 word (local_status != JPEG_HIP_OK) over the ranks, on the context's stream, and
+ * waits for it.  *failed_ranks receives the number of ranks that reported a failure. */
+int jpeg_hip_allreduce_status(jpeg_hip_ctx* ctx, void* rccl_comm, int local_status, int* failed_ranks);
+
 /* The exchange step alone, for callers that keep several images in flight with
  * jpeg_hip_analyze_band / jpeg_hip_finish_band_start / _wait: sums d_hist (uint64[4][256], as
  * jpeg_hip_analyze_band filled it) over the ranks in place, on the context's stream. */

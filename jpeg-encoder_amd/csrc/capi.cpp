@@ -574,6 +574,7 @@ const char* jpeg_hip_status_string(int status) {
         case JPEG_HIP_ERR_BUFFER_TOO_SMALL: return "buffer too small";
         case JPEG_HIP_ERR_BAD_STATE: return "entry points called out of order";
         case JPEG_HIP_ERR_NO_DEVICE: return "no usable GPU";
+        case JPEG_HIP_ERR_PEER_FAILED: return "another rank of the sharded encode failed";
         default: return "unknown status";
     }
 }
@@ -611,7 +612,7 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->gmask, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->groupSum, &ctx->result,
                       &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart,
                       &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum, &ctx->pixelsF, &ctx->pipeIn[0], &ctx->pipeIn[1],
-                      &ctx->pipeOut, &ctx->histDone, &ctx->gather, &ctx->joined, &ctx->repacked, &ctx->records, &ctx->recCount, &ctx->tileSlots};
+                      &ctx->pipeOut, &ctx->histDone, &ctx->gather, &ctx->joined, &ctx->repacked, &ctx->records, &ctx->recCount, &ctx->tileSlots, &ctx->exchange};
     delete ctx->decoded;
     delete ctx->workers;
     delete ctx->packers;
@@ -635,6 +636,7 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     for (HostBuf* b : hbufs) b->release();
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->orderEvent) (void)hipEventDestroy(ctx->orderEvent);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -643,6 +645,26 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
 const char* jpeg_hip_last_error(const jpeg_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 void* jpeg_hip_stream(jpeg_hip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int jpeg_hip_wait_for_stream(jpeg_hip_ctx* ctx, void* hip_stream) {
+    if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if ((hipStream_t)hip_stream == ctx->stream) return JPEG_HIP_OK;
+    ENTER_DEVICE(ctx);
+    if (!ctx->orderEvent) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->orderEvent, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->orderEvent, (hipStream_t)hip_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->orderEvent, 0));
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_stream_wait_for_ctx(jpeg_hip_ctx* ctx, void* hip_stream) {
+    if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    if ((hipStream_t)hip_stream == ctx->stream) return JPEG_HIP_OK;
+    ENTER_DEVICE(ctx);
+    if (!ctx->orderEvent) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->orderEvent, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->orderEvent, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent((hipStream_t)hip_stream, ctx->orderEvent, 0));
+    return JPEG_HIP_OK;
+}
 
 int jpeg_hip_compute_layout(const jpeg_hip_params* params, jpeg_hip_layout* out) {
     if (!params || !out) return JPEG_HIP_ERR_INVALID_ARGUMENT;

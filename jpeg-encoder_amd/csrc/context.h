@@ -83,6 +83,7 @@ struct Pinned {
     uint32_t tables[4 * 256];           // tables and header travel to the device in one copy
     uint8_t header[kHeaderCapacity];
     uint64_t result[4];
+    uint64_t exchangeFlag;              // failure flags of a sharded encode, to and from the device
 };
 
 // Host threads that stay around between batch passes: starting sixteen threads costs more
@@ -230,6 +231,8 @@ struct jpeg_hip_ctx {
     jpeghip::DevBuf records, recCount;                    // symbol records of the current coefficients (launch_symbol_records)
     uint32_t recGeneration = 0;                  // number of the last launch that wrote them
     bool recordsValid = false;                   // they belong to the current coefficients
+    jpeghip::DevBuf exchange;                             // histograms + failure flags a sharded encode all-reduces (sharded.cpp)
+    hipEvent_t orderEvent = nullptr;             // orders the context's stream against a caller's (jpeg_hip_wait_for_stream)
     jpeghip::DevBuf histDone;                             // counter of the histogram kernel's host export
     unsigned long long histExpected = 0;         // value of that counter once every launch so far has finished
     bool histOnHost = false;                     // pin->hist holds the current band's histograms as counted

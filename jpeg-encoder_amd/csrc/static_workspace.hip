@@ -22,6 +22,8 @@ static __device__ __align__(256) unsigned char scratch[kStaticWorkspaceBytes];
 constexpr int kMaxDevices = 64;
 std::mutex g_lock;
 unsigned char* g_scratchOnDevice[kMaxDevices] = {};
+// One call at a time per GPU: every context on a GPU borrows the same array.
+std::mutex g_inUse[kMaxDevices];
 
 }  // namespace
 
@@ -63,7 +65,6 @@ struct Loan {
     DevBuf* slot[kCount];
     DevBuf saved[kCount];
     unsigned long long savedExpected;
-    bool savedQtabOnDevice;
     explicit Loan(jpeg_hip_ctx* c) : ctx(c) {
         DevBuf* all[kCount] = {&c->coef, &c->qtab, &c->hist, &c->tables, &c->ivOff, &c->ffCount, &c->groupSum, &c->result,
                                &c->unstuffed, &c->tileState, &c->histDone, &c->gmask};
@@ -72,7 +73,6 @@ struct Loan {
             saved[i] = *all[i];
         }
         savedExpected = c->histExpected;
-        savedQtabOnDevice = c->qtabOnDevice;
     }
     void lend(DevBuf& b, unsigned char*& cursor, size_t bytes) {
         b.p = cursor;
@@ -139,6 +139,9 @@ int jpeg_hip_encode_static(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_form
 
     int st;
     {
+        // Held until the call's kernels have finished (the entry point waits for them): a second
+        // caller on this GPU, from any context or thread, waits here instead of racing on the array.
+        std::lock_guard<std::mutex> inUse(g_inUse[ctx->device]);
         Loan loan(ctx);
         unsigned char* cursor = base;
         loan.lend(ctx->coef, cursor, sz.coef);

@@ -5,6 +5,7 @@ raise.  Device pointers are plain integers (e.g. ``torch.Tensor.data_ptr()``).
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -13,13 +14,14 @@ LIB_PATH = os.path.abspath(os.path.join(_PKG, "..", "..", "lib", "libjpegenc_hip
 
 OK = 0
 FILTER_SEPIA, FILTER_MULTIPLY = 0, 1
-ERR_INVALID_ARGUMENT, ERR_HIP, ERR_BUFFER_TOO_SMALL, ERR_BAD_STATE, ERR_NO_DEVICE = -1, -2, -3, -4, -5
+ERR_INVALID_ARGUMENT, ERR_HIP, ERR_BUFFER_TOO_SMALL, ERR_BAD_STATE, ERR_NO_DEVICE, ERR_PEER_FAILED = -1, -2, -3, -4, -5, -6
 RGB8, RGBF32 = 0, 1
 STAGE_YCBCR, STAGE_SUBSAMPLE, STAGE_ALL = 1, 2, 3
 DC, AC = 0, 1
 
 EXPORTS = [
     "jpeg_hip_create", "jpeg_hip_destroy", "jpeg_hip_last_error", "jpeg_hip_status_string", "jpeg_hip_stream",
+    "jpeg_hip_wait_for_stream", "jpeg_hip_stream_wait_for_ctx", "jpeg_hip_allreduce_status",
     "jpeg_hip_compute_layout", "jpeg_hip_encode", "jpeg_hip_encode_static", "jpeg_hip_static_workspace_bytes", "jpeg_hip_encode_host", "jpeg_hip_encode_batch", "jpeg_hip_encode_batch_host", "jpeg_hip_begin", "jpeg_hip_upload_pixels", "jpeg_hip_upload_planes",
     "jpeg_hip_bind_pixels", "jpeg_hip_transform", "jpeg_hip_histograms", "jpeg_hip_histograms_host",
     "jpeg_hip_huffman_from_histogram", "jpeg_hip_huffman_from_histogram_limit", "jpeg_hip_standard_huffman", "jpeg_hip_write_dht", "jpeg_hip_write_headers", "jpeg_hip_set_huffman",
@@ -83,6 +85,9 @@ def lib():
         L.jpeg_hip_status_string.restype = C.c_char_p
         L.jpeg_hip_stream.argtypes = [vp]
         L.jpeg_hip_stream.restype = vp
+        L.jpeg_hip_wait_for_stream.argtypes = [vp, vp]
+        L.jpeg_hip_stream_wait_for_ctx.argtypes = [vp, vp]
+        L.jpeg_hip_allreduce_status.argtypes = [vp, vp, i32, C.POINTER(i32)]
         L.jpeg_hip_compute_layout.argtypes = [C.POINTER(Params), C.POINTER(Layout)]
         L.jpeg_hip_encode.argtypes = [vp, vp, i32, i64, C.POINTER(Params), vp, i64, C.POINTER(i64)]
         L.jpeg_hip_encode_host.argtypes = [vp, vp, i32, i64, C.POINTER(Params), vp, i64, C.POINTER(i64)]
@@ -293,8 +298,45 @@ class Context:
     def stream(self):
         return lib().jpeg_hip_stream(self._h)
 
+    # ---- ordering against the caller's stream ----
+    def wait_for_stream(self, hip_stream):
+        """Everything the context launches from now on waits for what is queued on hip_stream (an integer handle, 0 = default stream)."""
+        self._check(lib().jpeg_hip_wait_for_stream(self._h, C.c_void_p(hip_stream)))
+
+    def stream_wait_for_ctx(self, hip_stream):
+        """hip_stream waits for what the context has launched so far."""
+        self._check(lib().jpeg_hip_stream_wait_for_ctx(self._h, C.c_void_p(hip_stream)))
+
+    def _torch_stream(self):
+        # Only when the process uses torch on a GPU: device pointers handed to this class are then
+        # tensors torch fills, uploads and reads on its current stream, while the library works
+        # on the context's own.
+        torch = sys.modules.get("torch")
+        if torch is None or not torch.cuda.is_initialized():
+            return None
+        return torch.cuda.current_stream(self.device)
+
+    def _after_torch(self):
+        """Called before handing a device pointer to the library: orders the context's stream
+        behind torch's pending work (a fill or an upload that is still running would otherwise
+        race with the library's kernels).  An idle stream needs nothing."""
+        s = self._torch_stream()
+        if s is not None and not s.query():
+            self.wait_for_stream(s.cuda_stream)
+
+    def release_to_torch(self):
+        """For the caller to use after an entry point that returns before its kernels have
+        finished (transform, histograms_device, analyze_band, allreduce_histograms): torch's
+        current stream waits for them, so tensors they write can be used by torch right away.
+        Not done automatically: an event in the context's stream costs the host and the GPU some
+        ten microseconds, which a caller that goes on with finish_band has no use for."""
+        s = self._torch_stream()
+        if s is not None:
+            self.stream_wait_for_ctx(s.cuda_stream)
+
     # ---- one shot ----
     def encode(self, d_rgb, fmt, stride, params, d_out, capacity):
+        self._after_torch()
         n = C.c_int64(0)
         self._check(lib().jpeg_hip_encode(self._h, C.c_void_p(d_rgb), fmt, stride, C.byref(params), C.c_void_p(d_out),
                                           capacity, C.byref(n)))
@@ -302,6 +344,7 @@ class Context:
 
     def encode_static(self, d_rgb, fmt, stride, params, d_out, capacity):
         """jpeg_hip_encode on the library's fixed workspace: allocates no device memory."""
+        self._after_torch()
         n = C.c_int64(0)
         self._check(lib().jpeg_hip_encode_static(self._h, C.c_void_p(d_rgb), fmt, stride, C.byref(params),
                                                  C.c_void_p(d_out), capacity, C.byref(n)))
@@ -309,6 +352,7 @@ class Context:
 
     def encode_batch(self, d_rgb, fmt, stride, image_stride, count, params, d_out, slot_bytes):
         """`count` images of one shape, all resident in HBM -> int64 array of file lengths."""
+        self._after_torch()
         lens = np.zeros(count, np.int64)
         self._check(lib().jpeg_hip_encode_batch(self._h, C.c_void_p(d_rgb), fmt, stride, image_stride, count,
                                                 C.byref(params), C.c_void_p(d_out), slot_bytes, _np(lens)))
@@ -362,12 +406,14 @@ class Context:
         self._check(lib().jpeg_hip_upload_planes(self._h, *[C.c_void_p(p.ctypes.data) for p in planes], stride))
 
     def bind_pixels(self, d_rgb, fmt, stride):
+        self._after_torch()
         self._check(lib().jpeg_hip_bind_pixels(self._h, C.c_void_p(d_rgb), fmt, stride))
 
     def transform(self, stages=STAGE_ALL):
         self._check(lib().jpeg_hip_transform(self._h, stages))
 
     def histograms_device(self, d_hist):
+        self._after_torch()
         self._check(lib().jpeg_hip_histograms(self._h, C.c_void_p(d_hist)))
 
     def histograms(self):
@@ -391,6 +437,7 @@ class Context:
         return lengths, codes
 
     def emit_scan(self, d_out, capacity):
+        self._after_torch()
         n = C.c_int64(0)
         self._check(lib().jpeg_hip_emit_scan(self._h, C.c_void_p(d_out), capacity, C.byref(n)))
         return n.value
@@ -410,20 +457,30 @@ class Context:
 
     # ---- bands ----
     def analyze_band(self, d_rgb, fmt, stride, params, d_hist):
+        self._after_torch()
         self._check(lib().jpeg_hip_analyze_band(self._h, C.c_void_p(d_rgb), fmt, stride, C.byref(params),
                                                 C.c_void_p(d_hist)))
 
     def encode_sharded(self, comm, d_rgb, fmt, stride, params, d_out, capacity):
         """This rank's piece of a sharded image: analyze, all-reduce of the histograms over `comm`, finish."""
+        self._after_torch()
         n = C.c_int64(0)
         self._check(lib().jpeg_hip_encode_sharded(self._h, comm.handle, C.c_void_p(d_rgb), fmt, stride, C.byref(params),
                                                   C.c_void_p(d_out), capacity, C.byref(n)))
         return n.value
 
     def allreduce_histograms(self, comm, d_hist):
+        self._after_torch()
         self._check(lib().jpeg_hip_allreduce_histograms(self._h, comm.handle, C.c_void_p(d_hist)))
 
+    def allreduce_status(self, comm, local_status):
+        """Number of ranks of `comm` that report a failure (local_status != OK); a collective."""
+        n = C.c_int(0)
+        self._check(lib().jpeg_hip_allreduce_status(self._h, comm.handle, int(local_status), C.byref(n)))
+        return n.value
+
     def finish_band(self, d_hist_sum, d_out, capacity):
+        self._after_torch()
         n = C.c_int64(0)
         # d_hist_sum None: the band is the whole image, use the histograms as analyze_band counted them
         self._check(lib().jpeg_hip_finish_band(self._h, C.c_void_p(d_hist_sum) if d_hist_sum else None, C.c_void_p(d_out), capacity,
@@ -431,6 +488,7 @@ class Context:
         return n.value
 
     def finish_band_start(self, d_hist_sum, d_out, capacity):
+        self._after_torch()
         self._check(lib().jpeg_hip_finish_band_start(self._h, C.c_void_p(d_hist_sum) if d_hist_sum else None,
                                                      C.c_void_p(d_out), capacity))
 
@@ -467,6 +525,7 @@ class Context:
 
     def decode(self, jpeg, d_rgb, stride, capacity):
         """bytes -> RGB8 at device pointer d_rgb; returns ImageInfo."""
+        self._after_torch()
         buf = np.frombuffer(jpeg, np.uint8)
         info = ImageInfo()
         self._check(lib().jpeg_hip_decode(self._h, _np(buf), buf.size, C.c_void_p(d_rgb), stride, capacity,
@@ -480,6 +539,7 @@ class Context:
 
     def psnr(self, d_a, stride_a, d_b, stride_b, width, height):
         """(mse, psnr in dB) between two RGB8 images in device memory."""
+        self._after_torch()
         mse, psnr = C.c_double(0), C.c_double(0)
         self._check(lib().jpeg_hip_psnr(self._h, C.c_void_p(d_a), stride_a, C.c_void_p(d_b), stride_b, width, height,
                                         C.byref(mse), C.byref(psnr)))
@@ -487,6 +547,7 @@ class Context:
 
     def synthetic_images(self, kind, width, y0, y1, seed, d_out, stride, image_stride=0, count=1):
         """Rows y0..y1 of `count` synthetic RGB8 images (seeds seed, seed + 1, ...) into device memory."""
+        self._after_torch()
         self._check(lib().jpeg_hip_synthetic_images(self._h, {"noise": 0, "natural": 1}[kind], width, y0, y1,
                                                     seed & 0xFFFFFFFF, C.c_void_p(d_out), stride, image_stride, count))
 

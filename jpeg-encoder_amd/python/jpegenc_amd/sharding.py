@@ -33,6 +33,18 @@ def all_reduce_histograms(hist, group=None):
     return hist
 
 
+def failed_ranks(local_ok, group=None, device=None):
+    """One small collective after the pieces are written: how many ranks failed locally (an output
+    buffer too small for the piece, say).  Every rank gets the same number, so the job either keeps
+    all pieces or none."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([0 if local_ok else 1], dtype=torch.int64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return int(t.item())
+
+
 def concatenate_pieces(pieces):
     """File bytes from the per-band pieces in band order."""
     return b"".join(pieces)

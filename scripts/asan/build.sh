@@ -8,7 +8,7 @@ mkdir -p $OUT
   -Xarch_host -fsanitize=address -Xarch_host -fno-omit-frame-pointer -shared -o $OUT/libjpegenc_hip.so \
   jpeg-encoder_amd/csrc/capi.cpp jpeg-encoder_amd/csrc/sharded.cpp jpeg-encoder_amd/csrc/host_tables.cpp jpeg-encoder_amd/csrc/decode_host.cpp \
   jpeg-encoder_amd/csrc/kernels.hip jpeg-encoder_amd/csrc/entropy.hip jpeg-encoder_amd/csrc/decode_kernels.hip jpeg-encoder_amd/csrc/static_workspace.hip \
-  -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+  -ldl
 /opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++14 -ffp-contract=off -fPIC -fsanitize=address -fno-omit-frame-pointer -Ijpeg-encoder_amd/host -Iinclude \
   -shared -o $OUT/libjpegenc_host.so jpeg-encoder_amd/host/jpegenc_host.cpp -L$OUT -ljpegenc_hip -lz -Wl,-rpath,'$ORIGIN'
 for t in encode_jpeg host_selftest; do

@@ -29,6 +29,33 @@ def test_generator_matches_the_host_generators():
         ctx.close()
 
 
+def test_a_tensor_torch_is_still_filling_can_be_handed_over():
+    """The context works on its own stream; the binding orders it behind torch's current stream
+    whenever it is handed a device pointer (jpeg_hip_wait_for_stream).  Without that order the
+    zero fill below, queued behind a gigabyte-sized one, would run after the generator and wipe
+    its output (this happened once, with nothing but a small fill in the way)."""
+    ctx = B.Context(0)
+    try:
+        w, h = 2048, 1024
+        want = synth.generate("noise", w, h, seed=9)
+        for _ in range(4):
+            busy = torch.zeros(1 << 30, dtype=torch.uint8, device="cuda")     # keeps torch's stream busy for a while
+            out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")    # queued behind it
+            ctx.synthetic_images("noise", w, 0, h, 9, out.data_ptr(), w * 3)
+            assert np.array_equal(out.cpu().numpy(), want)
+            del busy
+        # and the other way round: a result of a call that returns early, read by torch at once
+        prm = B.make_params(w, h, T.SCHEME_420, T.quality_tables(90))
+        rgb = torch.from_numpy(want).cuda()
+        hist = torch.zeros((4, 256), dtype=torch.int64, device="cuda")
+        ctx.analyze_band(rgb.data_ptr(), B.RGB8, w * 3, prm, hist.data_ptr())
+        ctx.release_to_torch()
+        got = hist.cpu().numpy()
+        assert np.array_equal(got.view(np.uint64), ctx.histograms())
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("sname", ["444", "420"])
 def test_noise_q100_full_size(sname):
     w = h = 8192

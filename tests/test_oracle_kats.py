@@ -165,6 +165,21 @@ def test_oracle_output_hashes_unchanged():
     assert got == want
 
 
+def test_fullsize_fixture_is_what_the_oracle_writes():
+    """tests/golden/fullsize_hashes.json (what the GPU tests compare benchmark-size files with) holds
+    an entry for every case of the script that made it, and its 1080p and 4K entries are what both
+    restatements write today (the larger ones take minutes and are checked when the fixture is made)."""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_fullsize_hashes", os.path.join(here, "golden", "make_fullsize_hashes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "golden", "fullsize_hashes.json")))
+    assert sorted(want) == sorted(mod.CASES)
+    for name in ("1080p_420_annexk_natural", "1080p_420_q90_natural", "4k_444_q90_natural", "1080p_420_q90_frame9999"):
+        assert mod.entry(name) == want[name], name
+
+
 @pytest.mark.parametrize("scheme", sorted(T.SCHEMES))
 def test_vector_restatement_equals_scalar_one(scheme):
     """Larger and ragged images, every scheme (those with factors other than 1 and 2 take the

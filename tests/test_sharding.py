@@ -91,6 +91,45 @@ def test_two_rank_gloo_sharded_encode_matches_single_process():
     assert got == want
 
 
+def _cpu_failing_worker(rank, world, port, q):
+    """As _cpu_worker, but rank 1's output buffer is too small for its piece: the product's rule is
+    that every rank takes part in every collective and that one more small collective tells all of
+    them whether the file is complete."""
+    _init(rank, world, port)
+    try:
+        img = synth.generate("natural", W, H)
+        scheme, qt = T.SCHEMES[SCHEME], T.quality_tables(90)
+        whole = B.compute_layout(B.make_params(W, H, scheme, qt))
+        r0, r1 = sharding.band_rows(whole.mcu_rows, world, rank)
+        ri = sharding.row_restart_interval(whole.mcus_per_row)
+        band = img[r0 * whole.mcu_height:min(H, r1 * whole.mcu_height)]
+        own = O.encode(band, scheme, qt, restart_interval=ri)
+        hist = torch.from_numpy(own.hist.view(np.int64).copy())
+        sharding.all_reduce_histograms(hist)            # nobody leaves before the exchange
+        hsum = sharding.as_uint64(hist.numpy())
+        enc = O.encode(band, scheme, qt, restart_interval=ri, hist_override=hsum, rst_base=r0, header_height=H)
+        capacity = 10 if rank == 1 else 1 << 20
+        local_ok = len(enc.scan) + 2 <= capacity
+        failed = sharding.failed_ranks(local_ok)
+        q.put((rank, local_ok, failed))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_one_rank_fails_and_every_rank_learns_it():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cpu_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0          # nobody hung, nobody crashed
+    assert got == [(0, True, 1), (1, False, 1)]
+
+
 def test_band_rows_partition():
     for rows in (1, 7, 64, 1024):
         for world in (1, 2, 3, 4, 8):
@@ -244,4 +283,42 @@ def test_sharded_entry_point_over_an_rccl_communicator_of_one():
     finally:
         ctx.close()
         plain.close()
+        comm.close()
+
+
+@pytest.mark.gpu
+def test_sharded_entry_point_takes_part_in_the_exchange_when_its_own_step_fails():
+    """A rank whose local step fails (here: a row stride smaller than a row, which
+    jpeg_hip_analyze_band refuses) must still enter the all-reduce, with its failure flag up, and
+    return its own error afterwards; the communicator and the context serve the next image as if
+    nothing had happened.  With a world of one the rank's peers are absent, so what shows is that
+    the call returns the local status (not the peers' one) and leaves everything usable."""
+    dev = torch.device("cuda", 0)
+    qt = T.quality_tables(90)
+    comm = B.Communicator(B.comm_unique_id(), 0, 1, 0)
+    ctx = B.Context(0)
+    try:
+        w, h = 640, 360
+        img = synth.generate("natural", w, h, seed=5)
+        enc = sharding.HipBandEncoder(ctx, B, w, h, T.SCHEMES["420"], qt, 1, 0)
+        rgb = torch.from_numpy(img).to(dev)
+        out = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+        want = O.encode(img, T.SCHEMES["420"], qt, restart_interval=enc.params.restart_interval).jpeg
+        for _ in range(2):
+            with pytest.raises(B.JpegHipError) as e:
+                ctx.encode_sharded(comm, rgb.data_ptr(), B.RGB8, w * 3 - 1, enc.params, out.data_ptr(), out.numel())
+            assert e.value.status == B.ERR_INVALID_ARGUMENT and "stride" in str(e.value)
+            n = ctx.encode_sharded(comm, rgb.data_ptr(), B.RGB8, w * 3, enc.params, out.data_ptr(), out.numel())
+            assert out[:n].cpu().numpy().tobytes() == want
+        # a failure behind the exchange is local ...
+        with pytest.raises(B.JpegHipError) as e:
+            ctx.encode_sharded(comm, rgb.data_ptr(), B.RGB8, w * 3, enc.params, out.data_ptr(), 4096)
+        assert e.value.status == B.ERR_BUFFER_TOO_SMALL
+        # ... and the status collective tells every rank about it
+        assert ctx.allreduce_status(comm, e.value.status) == 1
+        assert ctx.allreduce_status(comm, B.OK) == 0
+        n = ctx.encode_sharded(comm, rgb.data_ptr(), B.RGB8, w * 3, enc.params, out.data_ptr(), out.numel())
+        assert out[:n].cpu().numpy().tobytes() == want
+    finally:
+        ctx.close()
         comm.close()

@@ -40,6 +40,18 @@ def test_static_workspace_matches_encode_twice_in_a_row():
         small = synth.generate("natural", 203, 117, seed=8)
         got, want = _encode_both(a, b, small, "420", qt)
         assert got == want
+        # Nothing is allocated: the device's free memory is the same before and after a call
+        # (inputs and outputs made beforehand, the plain context left alone).
+        prm = B.make_params(203, 117, T.SCHEMES["420"], qt)
+        dev = torch.device("cuda", 0)
+        rgb = torch.from_numpy(small).to(dev)
+        out = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(0)[0]
+        for _ in range(3):
+            n = a.encode_static(rgb.data_ptr(), B.RGB8, 203 * 3, prm, out.data_ptr(), out.numel())
+        assert torch.cuda.mem_get_info(0)[0] == free_before
+        assert out[:n].cpu().numpy().tobytes() == want
         # Other shapes of the path: 4:4:4, restart intervals, a second context on the same
         # array, the standard tables, an odd width (rows off 4-byte boundaries).
         got, want = _encode_both(b, a, synth.generate("natural", 640, 360, seed=9), "444", qt, restart_interval=5)
@@ -55,6 +67,44 @@ def test_static_workspace_matches_encode_twice_in_a_row():
         b.close()
 
 
+def test_static_workspace_serves_threads_one_at_a_time():
+    """Two threads, two contexts, one GPU and so one array: the calls take turns inside the library."""
+    import threading
+    qt = T.quality_tables(90)
+    imgs = [synth.generate("natural", 640, 360, seed=21), synth.generate("noise", 500, 300, seed=22)]
+    plain = B.Context(0)
+    want = [plain.encode_host(im, B.make_params(im.shape[1], im.shape[0], T.SCHEMES["420"], qt)) for im in imgs]
+    plain.close()
+    dev = torch.device("cuda", 0)
+    bad = []
+
+    def work(k):
+        ctx = B.Context(0)
+        try:
+            im = imgs[k]
+            h, w = im.shape[:2]
+            prm = B.make_params(w, h, T.SCHEMES["420"], qt)
+            rgb = torch.from_numpy(im).to(dev)
+            out = torch.zeros(1 << 20, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            for _ in range(40):
+                n = ctx.encode_static(rgb.data_ptr(), B.RGB8, w * 3, prm, out.data_ptr(), out.numel())
+                if out[:n].cpu().numpy().tobytes() != want[k]:
+                    bad.append(k)
+                    break
+        except Exception as e:      # reported through the list: an assertion in a thread is lost
+            bad.append((k, repr(e)))
+        finally:
+            ctx.close()
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not bad, bad
+
+
 def test_static_workspace_rejects_what_does_not_fit():
     ctx = B.Context(0)
     try:
@@ -67,5 +117,10 @@ def test_static_workspace_rejects_what_does_not_fit():
         with pytest.raises(B.JpegHipError) as e:
             ctx.encode_static(rgb.data_ptr(), B.RGB8, w * 3, prm, out.data_ptr(), out.numel())
         assert e.value.status == B.ERR_BUFFER_TOO_SMALL and "static workspace" in str(e.value)
+        # with the standard tables the array has to hold the worst-case stream: 1080p 4:4:4 does not fit
+        prm = B.make_params(1920, 1080, T.SCHEMES["444"], qt, standard_huffman=True)
+        with pytest.raises(B.JpegHipError) as e:
+            ctx.encode_static(rgb.data_ptr(), B.RGB8, 1920 * 3, prm, out.data_ptr(), out.numel())
+        assert e.value.status == B.ERR_BUFFER_TOO_SMALL and "worst-case" in str(e.value)
     finally:
         ctx.close()
