@@ -389,17 +389,14 @@ def main():
         c.finish_band_start(h.data_ptr() if world > 1 else None, o.data_ptr(), cap)
 
     def wait(k, acc):
-        n = lanes[k][0].finish_band_wait()
-        if acc is not None:
-            acc += lanes[k][0].timings()
-        return n
+        return lanes[k][0].finish_band_wait()
 
     def run(count, acc, depth=depth):
         n = 0
         if depth == 1:
             for _ in range(count):
                 n = step()
-                if acc is not None:
+                if acc is not None and batch:
                     acc += ctx.timings()
             return n
         if depth == 2:
@@ -426,15 +423,36 @@ def main():
     n_out = run(args.warmup, None)
     sync()
     kern_ms = np.zeros(4)
+    host_tl = np.zeros(8)
+    for lane in lanes:
+        lane[0].set_profiling(True)      # clears the sums the library keeps per context
     t0 = time.perf_counter()
     n_out = run(args.steps, kern_ms)
     sync()
     elapsed = time.perf_counter() - t0
+    if not batch:       # single images: the library has added up stage times and host stations itself
+        for lane in lanes:
+            ms, us, _ = lane[0].profile_sums()
+            kern_ms += ms
+            host_tl += us
+    own_elapsed = elapsed
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     kern_ms /= max(args.steps, 1)
+    host_tl /= max(args.steps, 1)
+    # Every rank's own figures, for reading a scaling curve: the kernels of its band, the
+    # stations of its host, its step time.
+    mine = {"rank": rank, "ms_per_step": round(own_elapsed / max(args.steps, 1) * 1e3, 4),
+            "stage_ms": {"transform": round(float(kern_ms[0]), 4), "histogram": round(float(kern_ms[1]), 4),
+                         "entropy": round(float(kern_ms[2]), 4), "host_tables": round(float(kern_ms[3]), 4)},
+            "host_us": dict(zip(["launch_analyze", "to_finish (exchange)", "wait_histograms", "tables_header", "launch_entropy",
+                                 "to_wait", "wait_result", "between_steps"], [round(float(v), 1) for v in host_tl]))}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         mp = width * height / 1e6 * (batch * world if batch else 1)
@@ -471,6 +489,7 @@ def main():
             "roofline_stages": stage_rooflines(lay, max(batch, 1), int(n_out), kern_ms),
             "stage_ms": {"transform": round(float(kern_ms[0]), 4), "histogram": round(float(kern_ms[1]), 4),
                          "entropy": round(float(kern_ms[2]), 4), "host_tables": round(float(kern_ms[3]), 4)},
+            "per_rank": per_rank,
         }
         if not args.no_cpu_baseline and world == 1:
             def gpu_file(i):

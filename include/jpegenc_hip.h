@@ -371,6 +371,19 @@ void jpeg_hip_comm_destroy(void* comm);
  * Only filled while profiling is enabled. */
 int jpeg_hip_set_profiling(jpeg_hip_ctx* ctx, int enabled);
 int jpeg_hip_get_timings(jpeg_hip_ctx* ctx, float out_ms[4]);
+/* Where the host was, and when, during the last jpeg_hip_analyze_band / jpeg_hip_finish_band
+ * (or the one-call entry points built from them): microseconds of the steady clock at [0]
+ * analyze entered, [1] transform and histogram kernels launched, [2] finish entered (behind the
+ * caller's exchange step, if any), [3] histograms seen on the host, [4] tables and header built,
+ * [5] entropy kernels launched, [6] wait for the result entered, [7] result seen.  The gaps
+ * the kernel timings do not explain are here.  Only filled while profiling is enabled. */
+int jpeg_hip_get_host_timeline(jpeg_hip_ctx* ctx, double out_us[8]);
+/* The same figures added up over the single images encoded since jpeg_hip_set_profiling(ctx, 1)
+ * was last called (which clears the sums): stage_ms as jpeg_hip_get_timings, host_us[0..6] the
+ * seven intervals between the stations of jpeg_hip_get_host_timeline, host_us[7] the time from
+ * one image's result to the next image's entry, *images the number of images.  For loops in
+ * which asking after every image would cost more than the answer is worth. */
+int jpeg_hip_get_profile_sums(jpeg_hip_ctx* ctx, double stage_ms[4], double host_us[8], int64_t* images);
 
 /* ---- verification decoder ---------------------------------------------------------------- */
 

@@ -239,6 +239,12 @@ int ensure_workspace(jpeg_hip_ctx* ctx, int images = 1) {
     return JPEG_HIP_OK;
 }
 
+// Host clock at the stations of an encode (jpeg_hip_get_host_timeline), while profiling is on.
+void tick(jpeg_hip_ctx* ctx, int i) {
+    if (ctx->profiling)
+        ctx->hostTimeline[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 void mark(jpeg_hip_ctx* ctx, int i) {
     if (ctx->profiling) (void)hipEventRecord(ctx->ev[i], ctx->stream);
 }
@@ -380,9 +386,6 @@ int run_entropy_launch(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_
         HIP_TRY(ctx, ctx->tileSlots.ensure((size_t)group_slot_bytes(ctx->kg)));
         ctx->ws.tileSlots = (uint32_t*)ctx->tileSlots.p;
     }
-    ctx->ws.records = ctx->recordsValid ? (const uint32_t*)ctx->records.p : nullptr;
-    ctx->ws.recCount = (const uint32_t*)ctx->recCount.p;
-    ctx->ws.recGeneration = ctx->recGeneration;
     ctx->ws.header = (const uint8_t*)ctx->tables.p + sizeof ctx->pin->tables;
     ctx->ws.headerLen = (int)prefix;
     // A header staged with the tables is fetched with them; a launch without header (a
@@ -404,22 +407,25 @@ int run_entropy_launch(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_
 
 int run_entropy_wait(jpeg_hip_ctx* ctx, int64_t* outLen) {
     HIP_TRY(ctx, wait_stream(ctx));
+    tick(ctx, 7);
     if (ctx->profiling) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->times[0] = ms;
         if (hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]) == hipSuccess) ctx->times[1] = ms;
         if (hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]) == hipSuccess) ctx->times[2] = ms;
+        // Sums over the images since profiling was switched on, so that a caller in a tight loop
+        // reads them once at the end instead of after every image.
+        for (int i = 0; i < 4; ++i) ctx->sumTimes[i] += ctx->times[i];
+        for (int i = 0; i < 7; ++i) ctx->sumTimeline[i] += ctx->hostTimeline[i + 1] - ctx->hostTimeline[i];
+        if (ctx->lastResultSeen > 0) ctx->sumTimeline[7] += ctx->hostTimeline[0] - ctx->lastResultSeen;
+        ctx->lastResultSeen = ctx->hostTimeline[7];
+        ++ctx->sumCount;
     }
     // What the bit writer reports beside its bytes: 2 the chain of tiles broke, 4 the stream ran
     // past the part of the buffer that was cleared for it, 8 a tile's bits did not fit its
     // stage, 16 a symbol occurred that the tables have no code for.  4 and 8 are cured by running
-    // the stage again with a full clear / with smaller tiles; 32: the symbol records are
-    // incomplete (a slot was too small), cured by coding from the coefficients.
-    for (int attempt = 0; attempt < 5 && (ctx->pin->result[3] & (4 | 8 | 32)) != 0 && (ctx->pin->result[3] & (2 | 16)) == 0; ++attempt) {
-        if (ctx->pin->result[3] & 32) {
-            ctx->recordsValid = false;
-            ctx->ws.records = nullptr;
-        }
+    // the stage again with a full clear / with smaller tiles.
+    for (int attempt = 0; attempt < 5 && (ctx->pin->result[3] & (4 | 8)) != 0 && (ctx->pin->result[3] & (2 | 16)) == 0; ++attempt) {
         if (ctx->pin->result[3] & 4) ctx->streamBits = -1;
         if (ctx->pin->result[3] & 8) ctx->ws.groupTile = ctx->ws.groupTile > 64 ? 64 : (ctx->ws.groupTile > 16 ? 16 : 0);
         ctx->ws.pendingTables = nullptr;   // tables and header are on the device by now
@@ -428,7 +434,7 @@ int run_entropy_wait(jpeg_hip_ctx* ctx, int64_t* outLen) {
         HIP_TRY(ctx, wait_stream(ctx));
     }
     if (ctx->pin->result[3] & 16) return fail(ctx, JPEG_HIP_ERR_INVALID_ARGUMENT, "the Huffman tables have no code for a symbol of this image");
-    if (ctx->pin->result[3] & (4 | 8 | 32)) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer could not place its stream");
+    if (ctx->pin->result[3] & (4 | 8)) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer could not place its stream");
     if (ctx->pin->result[2] != 0 || (ctx->pin->result[3] & 2)) return fail(ctx, JPEG_HIP_ERR_HIP, "the bit writer's tiles lost their chain");
     if (ctx->pin->result[1] != 0) return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL, "output buffer is too small for the scan");
     *outLen = (int64_t)ctx->pin->result[0];
@@ -498,7 +504,6 @@ int do_transform(jpeg_hip_ctx* ctx, int stages, bool staged = false, uint64_t* c
     mark(ctx, 1);
     ctx->transformed = true;
     ctx->stagedScanLen = -1;
-    ctx->recordsValid = false;
     // Whatever histograms the installed tables came from, they did not count these
     // coefficients: the bit count derived from them bounds nothing any more.
     ctx->streamBits = -1;
@@ -521,25 +526,8 @@ int do_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist, bool cleared = false, boo
         ex.expected = ctx->histExpected;
         ex.host = (unsigned long long*)ctx->pin->hist;
     }
-    ctx->recordsValid = false;
-    if (!ctx->staticWorkspace && records_path_takes(ctx->kg)) {
-        // One pass for the histograms and for the records the bit writer will code from.
-        const size_t tiles = (size_t)records_tiles(ctx->kg);
-        HIP_TRY(ctx, ctx->records.ensure(tiles * kRecordsPerTile * sizeof(uint32_t)));
-        if (ctx->recCount.cap < (tiles + 1) * sizeof(uint32_t)) {
-            HIP_TRY(ctx, ctx->recCount.ensure((tiles + 1) * sizeof(uint32_t)));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->recCount.p, 0, sizeof(uint32_t), ctx->stream));   // the overflow word
-            ctx->recGeneration = 0;
-        }
-        ++ctx->recGeneration;
-        HIP_TRY(ctx, launch_symbol_records(ctx->kg, (const int16_t*)ctx->coef.p, (unsigned long long*)d_hist, ctx->stream, !cleared,
-                                           toHost ? &ex : nullptr, (uint32_t*)ctx->records.p, (uint32_t*)ctx->recCount.p,
-                                           ctx->recGeneration));
-        ctx->recordsValid = true;
-    } else {
-        HIP_TRY(ctx, launch_histogram(ctx->kg, (const int16_t*)ctx->coef.p, (unsigned long long*)d_hist, ctx->stream, !cleared,
-                                      toHost ? &ex : nullptr));
-    }
+    HIP_TRY(ctx, launch_histogram(ctx->kg, (const int16_t*)ctx->coef.p, (unsigned long long*)d_hist, ctx->stream, !cleared,
+                                  toHost ? &ex : nullptr));
     if (toHost) {
         ctx->histExpected = ex.expected;
         ctx->histOnHost = true;
@@ -554,11 +542,13 @@ int fetch_hist_and_build(jpeg_hip_ctx* ctx, const uint64_t* d_hist, int64_t capa
     if (!d_hist) {   // the band's own histograms, which the kernel has put into the pinned block
         if (!ctx->histOnHost) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "no histograms of this band: pass the summed ones");
         HIP_TRY(ctx, wait_stream(ctx));
+        tick(ctx, 3);
         return build_tables(ctx, ctx->pin->hist, true, capacity, headerLen);
     }
     ctx->histOnHost = false;   // the pinned block is about to hold the caller's histograms
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pin->hist, d_hist, sizeof ctx->pin->hist, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, wait_stream(ctx));
+    tick(ctx, 3);
     return build_tables(ctx, ctx->pin->hist, true, capacity, headerLen);
 }
 
@@ -612,7 +602,7 @@ void jpeg_hip_destroy(jpeg_hip_ctx* ctx) {
     DevBuf* bufs[] = {&ctx->pixels, &ctx->coef, &ctx->gmask, &ctx->qtab, &ctx->hist, &ctx->tables, &ctx->ivOff, &ctx->ffCount, &ctx->groupSum, &ctx->result,
                       &ctx->unstuffed, &ctx->staging, &ctx->batchHdr, &ctx->batchHdrLen, &ctx->batchFfStart,
                       &ctx->tileState, &ctx->decCoef, &ctx->decPlanes, &ctx->decTables, &ctx->decRgb, &ctx->decSum, &ctx->pixelsF, &ctx->pipeIn[0], &ctx->pipeIn[1],
-                      &ctx->pipeOut, &ctx->histDone, &ctx->gather, &ctx->joined, &ctx->repacked, &ctx->records, &ctx->recCount, &ctx->tileSlots, &ctx->exchange};
+                      &ctx->pipeOut, &ctx->histDone, &ctx->gather, &ctx->joined, &ctx->repacked, &ctx->tileSlots, &ctx->exchange};
     delete ctx->decoded;
     delete ctx->workers;
     delete ctx->packers;
@@ -1043,6 +1033,7 @@ const int16_t* jpeg_hip_coefficients_device(jpeg_hip_ctx* ctx) {
 int jpeg_hip_analyze_band(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_format, int64_t stride_bytes,
                           const jpeg_hip_params* params, uint64_t* d_hist) {
     if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    tick(ctx, 0);
     int st = jpeg_hip_begin(ctx, params);
     if (st != JPEG_HIP_OK) return st;
     st = jpeg_hip_bind_pixels(ctx, d_rgb, sample_format, stride_bytes);
@@ -1054,9 +1045,12 @@ int jpeg_hip_analyze_band(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_forma
     if (st != JPEG_HIP_OK) return st;
     if (!count) {
         mark(ctx, 2);
+        tick(ctx, 1);
         return JPEG_HIP_OK;
     }
-    return do_histograms(ctx, hist, true, true);
+    st = do_histograms(ctx, hist, true, true);
+    tick(ctx, 1);
+    return st;
 }
 
 int jpeg_hip_finish_band(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, uint8_t* d_out, int64_t out_capacity,
@@ -1072,11 +1066,14 @@ int jpeg_hip_finish_band_start(jpeg_hip_ctx* ctx, const uint64_t* d_hist_sum, ui
     if (!ctx->transformed) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "finish needs analyze");
     if (ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "jpeg_hip_finish_band_wait has not been called");
     ENTER_DEVICE(ctx);
+    tick(ctx, 2);
     int headerLen = 0;
     int st = fetch_hist_and_build(ctx, d_hist_sum, out_capacity, &headerLen);
     if (st != JPEG_HIP_OK) return st;
+    tick(ctx, 4);
     st = run_entropy_launch(ctx, d_out, headerLen, out_capacity, ctx->geo.endsImage ? 1 : 0);
     if (st != JPEG_HIP_OK) return st;
+    tick(ctx, 5);
     ctx->scanInFlight = true;
     return JPEG_HIP_OK;
 }
@@ -1086,6 +1083,7 @@ int jpeg_hip_finish_band_wait(jpeg_hip_ctx* ctx, int64_t* out_len) {
     if (!ctx->scanInFlight) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "no jpeg_hip_finish_band_start to wait for");
     ENTER_DEVICE(ctx);
     ctx->scanInFlight = false;
+    tick(ctx, 6);
     return run_entropy_wait(ctx, out_len);
 }
 
@@ -1130,6 +1128,24 @@ int jpeg_hip_encode_host(jpeg_hip_ctx* ctx, const void* h_rgb, int sample_format
 int jpeg_hip_set_profiling(jpeg_hip_ctx* ctx, int enabled) {
     if (!ctx) return JPEG_HIP_ERR_INVALID_ARGUMENT;
     ctx->profiling = enabled != 0;
+    for (auto& v : ctx->sumTimes) v = 0;
+    for (auto& v : ctx->sumTimeline) v = 0;
+    ctx->sumCount = 0;
+    ctx->lastResultSeen = 0;
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_get_host_timeline(jpeg_hip_ctx* ctx, double out_us[8]) {
+    if (!ctx || !out_us) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    memcpy(out_us, ctx->hostTimeline, sizeof ctx->hostTimeline);
+    return JPEG_HIP_OK;
+}
+
+int jpeg_hip_get_profile_sums(jpeg_hip_ctx* ctx, double stage_ms[4], double host_us[8], int64_t* images) {
+    if (!ctx || !stage_ms || !host_us || !images) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    memcpy(stage_ms, ctx->sumTimes, sizeof ctx->sumTimes);
+    memcpy(host_us, ctx->sumTimeline, sizeof ctx->sumTimeline);
+    *images = ctx->sumCount;
     return JPEG_HIP_OK;
 }
 
@@ -1257,7 +1273,6 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
             h.coef = (const int16_t*)ctx->coef.p + (int64_t)h.a * g.totalBlocks * (k.coefPitch / 2);
             h.tables = (const uint32_t*)ctx->tables.p + (h.k.tableStride ? (size_t)h.a * 1024 : 0);
             h.ws = ctx->ws;
-            h.ws.records = nullptr;
             h.ws.tileSlots = slots ? slots + (i == 1 ? group_slot_bytes(half[0].k) / 4 : 0) : nullptr;
             if (i == 1) {   // behind the first half's slices
                 h.ws.ivOff += firstCount + 1;

@@ -228,9 +228,6 @@ struct jpeg_hip_ctx {
     jpeghip::DevBuf joined;                               // all blocks with their halves joined (jpeg_hip_coefficients_device)
     jpeghip::DevBuf gather;                               // one channel's coefficients, contiguous (jpeg_hip_get_coefficients)
     jpeghip::DevBuf tileSlots;                            // staged bits of the bit writer's tiles (EntropyWorkspace::tileSlots)
-    jpeghip::DevBuf records, recCount;                    // symbol records of the current coefficients (launch_symbol_records)
-    uint32_t recGeneration = 0;                  // number of the last launch that wrote them
-    bool recordsValid = false;                   // they belong to the current coefficients
     jpeghip::DevBuf exchange;                             // histograms + failure flags a sharded encode all-reduces (sharded.cpp)
     hipEvent_t orderEvent = nullptr;             // orders the context's stream against a caller's (jpeg_hip_wait_for_stream)
     jpeghip::DevBuf histDone;                             // counter of the histogram kernel's host export
@@ -258,6 +255,11 @@ struct jpeg_hip_ctx {
     bool profiling = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float times[4] = {0, 0, 0, 0};
+    double hostTimeline[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // jpeg_hip_get_host_timeline
+    double sumTimes[4] = {0, 0, 0, 0};                   // jpeg_hip_get_profile_sums: `times` added up
+    double sumTimeline[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // ... the seven intervals of hostTimeline, and the gap between images
+    double lastResultSeen = 0;                           // hostTimeline[7] of the image before
+    int64_t sumCount = 0;
 };
 
 #endif

@@ -717,47 +717,14 @@ static long long group_tiles_per_image(long long blocksPerImage, int tileBlocks)
     return ((blocksPerImage + tileBlocks - 1) / tileBlocks + 3) / 4 * 4;
 }
 
-#include "entropy_records.h"
-static_assert(kRecPerTile == kRecordsPerTile, "the host sizes the record slots");
-
 static long long group_min_blocks() {
     // (Diagnostic switch JPEGENC_GROUP_MIN_BLOCKS: another threshold, e.g. 0 to test it on small images.)
     const char* minEnv = getenv("JPEGENC_GROUP_MIN_BLOCKS");
     return minEnv ? atoll(minEnv) : kGrpMinBlocks;
 }
 
-// The two-pass form (entropy_records.h) is correct and tested, but not faster yet: for the
-// 16384 x 16384 4:2:0 image its first pass takes 302 us where k_histogram takes 203, and its
-// three light kernels 207 us where k_encode_groups takes 284 -- the records of a photographic image
-// are as many bytes as its non-empty groups of coefficients, so nothing is saved in traffic.  It
-// is therefore opt-in (JPEGENC_RECORDS=1): single images large enough for the kernels on groups,
-// restart intervals of sixteen blocks and more (or none).
-bool records_path_takes(const KGeom& g) {
-    const char* env = getenv("JPEGENC_RECORDS");   // read on every call: the tests switch it
-    return env != nullptr && env[0] == '1' && !old_entropy_kernels() && g.batch == 1 && g.totalBlocks >= group_min_blocks() &&
-           (g.intervals == 1 || g.mcusPerInterval * g.bpm >= kGrpMinIntervalBlocks) && g.intervals <= kRecMaxIntervals &&
-           g.groupMask != nullptr;
-}
-
-long long records_tiles(const KGeom& g) { return group_tiles_per_image(g.blocksPerImage, kGrpTileBlocks); }
-
 long long group_slot_bytes(const KGeom& g) {
     return group_tiles_per_image(g.blocksPerImage, kGrpTileBlocks) * g.batch * (long long)kGrpSlotWords * 4;
-}
-
-hipError_t launch_symbol_records(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, bool clear,
-                                 HistogramExport* ex, u32* d_records, u32* d_recCount, u32 generation) {
-    if (clear) {
-        const hipError_t e = launch_clear_histograms(d_hist, 1, s);
-        if (e != hipSuccess) return e;
-    }
-    const long long quads = records_tiles(g) / 4;
-    const long long grid = quads < 2048 ? quads : 2048;
-    HistogramExport none = {nullptr, 0, nullptr};
-    if (ex != nullptr) ex->expected += (unsigned long long)grid;   // what the counter reads when all are done
-    hipLaunchKernelGGL(k_symbol_records, dim3((unsigned)grid), dim3(256), 0, s, g, d_coef, d_hist, ex != nullptr ? *ex : none,
-                       d_records, d_recCount + 1, d_recCount, generation);
-    return hipGetLastError();
 }
 
 // kPrivate: blocks are short on average (photographic content), so the first walk keeps
@@ -1031,37 +998,7 @@ __device__ __forceinline__ u32 stuff_mask(const KGeom& g, const uint8_t* __restr
     return mask;
 }
 
-// One wave per 4 KiB chunk: four 16-byte pieces per lane in flight, a shuffle reduction, no
-// barriers.
 constexpr int kChunkGroup = 64;   // chunks whose counts are also kept as one sum
-
-__global__ __launch_bounds__(256) void k_count_ff(KGeom g, const uint8_t* __restrict__ buf,
-                                                  const u64* __restrict__ ivOff, const u64* __restrict__ result,
-                                                  u32* __restrict__ ffCount) {
-    const u64 bytes = result[2];
-    const long long chunks = (long long)((bytes + kStuffChunk - 1) / kStuffChunk);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (long long ch = (long long)blockIdx.x * 4 + wave; ch < chunks; ch += (long long)gridDim.x * 4) {
-        int cnt = 0;
-        bool marker = false;
-        uint4 q[kStuffChunk / 1024];
-#pragma unroll
-        for (int k = 0; k < kStuffChunk / 1024; ++k) {
-            const long long i0 = ch * kStuffChunk + k * 1024 + lane * 16;
-            q[k] = make_uint4(0, 0, 0, 0);
-            if ((u64)i0 < bytes) q[k] = *(const uint4*)(buf + i0);
-        }
-#pragma unroll
-        for (int k = 0; k < kStuffChunk / 1024; ++k) {
-            const long long i0 = ch * kStuffChunk + k * 1024 + lane * 16;
-            if ((u64)i0 < bytes) cnt += __popc(stuff_mask(g, buf, ivOff, bytes, i0, q[k], false, &marker));
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
-        const bool anyMarker = __ballot(marker) != 0;
-        if (lane == 0) ffCount[ch] = (u32)cnt | (anyMarker ? kChunkMarkerOne : 0u);
-    }
-}
 
 // For long streams: the counts of kChunkGroup consecutive chunks added up, one wave per sum.
 __global__ __launch_bounds__(256) void k_group_sums(const u32* __restrict__ ffCount, const u64* __restrict__ result,
@@ -1394,45 +1331,35 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     // is a longer chain than the image has work to hide (1080p: 37 -> 44 us).
     // (Diagnostic switch JPEGENC_GROUP_MIN_BLOCKS: another threshold, e.g. 0 to test it on small images.)
     const long long minBlocks = group_min_blocks();
-    const bool fromRecords = ws.records != nullptr && bo == nullptr;
     const bool groups = ws.groupTile > 0 && !old_entropy_kernels() && g.totalBlocks >= minBlocks &&
                         (g.intervals == g.batch || g.mcusPerInterval * g.bpm >= kGrpMinIntervalBlocks);
-    const long long tilesPerImage = fromRecords ? records_tiles(g)
-                                    : groups    ? group_tiles_per_image(g.blocksPerImage, ws.groupTile)
-                                                : (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
+    const long long tilesPerImage = groups ? group_tiles_per_image(g.blocksPerImage, ws.groupTile)
+                                           : (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
     const long long tileCount = tilesPerImage * g.batch;
     // The bit writer ORs into the stream, so the part it can reach starts out as zeros.
     long long zero = ws.streamBound < 0 ? ws.unstuffedCap : (ws.streamBound + kStuffChunk + 63) / 16 * 16;
     if (zero > ws.unstuffedCap) zero = ws.unstuffedCap;
     // (Not when the tiles' bits are placed by k_place_tiles and k_merge_edges: those write every
     // word of the stream exactly once, with plain stores.)
-    const bool deferred = !fromRecords && groups && ws.tileSlots != nullptr && ws.groupTile == kGrpTileBlocks;
+    const bool deferred = groups && ws.tileSlots != nullptr && ws.groupTile == kGrpTileBlocks;
     const long long clear16 = deferred ? 0 : zero / 16;
-    // Who keeps the per-chunk counts of 0xFF bytes: the kernels that write the stream, or (for the
-    // writer on symbol records) a pass of its own behind them.
+    // The kernels that write the stream keep the per-chunk counts of its 0xFF bytes.
     const bool shortBlocks = ws.avgBlockBits <= 128;   // long blocks (noise, q=100) do not fit the private words; unknown lengths count as short
-    const bool counted = !fromRecords;
     long long prepGrid = (clear16 > tileCount / 2 ? clear16 : tileCount / 2) / (256 * 4);
     prepGrid = prepGrid < 1 ? 1 : (prepGrid > 2048 ? 2048 : prepGrid);
     // Chunks the stream can have at most: from the bound that was cleared.
     long long chunkBound = zero / kStuffChunk + 1;
     if (chunkBound > ws.maxChunks) chunkBound = ws.maxChunks;
+    // Tile states: the chaining tiles start from zeros (and a zero ticket counter behind them); deferred
+    // tiles write theirs before anybody reads them, and only the word k_tile_positions counts its waves
+    // off with has to be zero.
+    const long long deferredRuns = (tileCount + 63) / 64;
+    u64* clearStates = deferred ? ws.tileState + tileCount + deferredRuns : ws.tileState;
+    const long long clearStateWords = deferred ? 1 : tileCount + 1;
     hipLaunchKernelGGL(k_prepare_entropy, dim3((unsigned)prepGrid), dim3(256), 0, s, (uint4*)ws.unstuffed, clear16,
-                       ws.tileState, tileCount + 1, ws.result, ws.header, bo ? 0 : ws.headerLen, d_out,
-                       bo ? nullptr : ws.pendingTables, const_cast<u32*>(d_tables), ws.ffCount, counted ? chunkBound : 0);
-    if (fromRecords) {
-        hipLaunchKernelGGL(k_record_lengths, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, ws.records, ws.recCount + 1,
-                           ws.recCount, ws.recGeneration, d_tables, ws.tileState, ws.result);
-        // (The run summaries live behind the tiles' own in the same buffer, which is sized for tiles of 16 blocks.)
-        const u32 runs = (u32)((tileCount + 63) / 64);
-        u64* runStart = ws.tileState + tileCount;
-        hipLaunchKernelGGL(k_group_positions, dim3(runs), dim3(64), 0, s, ws.tileState, runStart, (u32)tileCount);
-        hipLaunchKernelGGL(k_run_positions, dim3(1), dim3(1024), 0, s, g, runStart, runs);
-        hipLaunchKernelGGL(k_emit_records, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, ws.records, ws.recCount + 1,
-                           ws.recCount, ws.recGeneration, d_tables, ws.tileState, runStart, ws.ivOff, ws.result,
-                           (u32*)ws.unstuffed, zero);
-    }
-    else if (deferred) {
+                       clearStates, clearStateWords, ws.result, ws.header, bo ? 0 : ws.headerLen, d_out,
+                       bo ? nullptr : ws.pendingTables, const_cast<u32*>(d_tables), ws.ffCount, chunkBound);
+    if (deferred) {
         // Nobody waits: the tiles leave their bits in slots, two small kernels find where every
         // tile starts, a third puts the bits there (a tile that chains with a look-back spends a
         // quarter of its life waiting for the slowest of the thousands of tiles in front of it).
@@ -1440,8 +1367,8 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
                            ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero, ws.tileSlots, nullptr);
         const u32 runs = (u32)((tileCount + 63) / 64);
         u64* runStart = ws.tileState + tileCount;   // (the buffer is sized for tiles of 16 blocks)
-        hipLaunchKernelGGL(k_group_positions, dim3(runs), dim3(64), 0, s, ws.tileState, runStart, (u32)tileCount);
-        hipLaunchKernelGGL(k_run_positions, dim3(1), dim3(1024), 0, s, g, runStart, runs);
+        hipLaunchKernelGGL(k_tile_positions, dim3(runs), dim3(64), 0, s, g, ws.tileState, runStart, (u32)tileCount,
+                           runStart + runs);   // (a word the clearing kernel has zeroed)
         hipLaunchKernelGGL(k_place_tiles, dim3((unsigned)((tileCount + 3) / 4)), dim3(256), 0, s, g, ws.tileState, runStart,
                            ws.tileSlots, ws.ivOff, ws.result, (u32*)ws.unstuffed, (u32)tileCount, zero, ws.ffCount);
         hipLaunchKernelGGL(k_merge_edges, dim3((unsigned)((4 * tileCount + 255) / 256)), dim3(256), 0, s, g, ws.tileSlots,
@@ -1464,12 +1391,6 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
 
     long long chunkGrid = chunkBound < gridCap ? chunkBound : gridCap;
     if (chunkGrid < 1) chunkGrid = 1;
-    long long countGrid = (chunkBound + 3) / 4;
-    countGrid = countGrid < 1 ? 1 : (countGrid > 4096 ? 4096 : countGrid);
-    // (Not when the kernels that wrote the stream have counted its 0xFF bytes on the way.)
-    if (!counted)
-        hipLaunchKernelGGL(k_count_ff, dim3((unsigned)countGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff, ws.result,
-                           ws.ffCount);
     // Up to this many chunks a workgroup adds the counts in front of its first chunk up
     // directly (64 loads per thread at most); beyond, group sums come first.
     const u64* groupSum = nullptr;

@@ -848,6 +848,66 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
     if (flags != 0 && lane == 0) atomicOr((unsigned long long*)&result[1], (unsigned long long)flags);
 }
 
+__device__ __forceinline__ PosSummary wave_scan_summary(PosSummary inc) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        PosSummary o;
+        o.x = __shfl_up(inc.x, d, 64);
+        o.y = __shfl_up(inc.y, d, 64);
+        if (lane >= d) inc = pos_combine(o, inc);
+    }
+    return inc;
+}
+
+// Deferred placement, positions: the tiles' summaries to start positions, in one launch.  One wave
+// per run of 64 tiles replaces each tile's summary by the summary of the tiles in front of it
+// inside the run and notes the run's own summary; the wave that finishes last turns the runs'
+// summaries into the positions at which the runs start.  A tile then starts at
+// pos_apply(summary[tile], runSummary[tile / 64]).
+// `done` counts the waves that have finished and is zero at the start.  No fences (a release at
+// device scope writes a whole L2 back): a run's summary is put down with an exchange that
+// returns, so it has been performed when the wave counts itself off, and the last wave reads the
+// summaries where the exchanges were made.
+__global__ __launch_bounds__(64) void k_tile_positions(KGeom g, u64* __restrict__ summary, u64* __restrict__ runSummary,
+                                                       u32 tiles, u64* __restrict__ done) {
+    const int lane = threadIdx.x;
+    const u32 t = blockIdx.x * 64u + (u32)lane;
+    const u64 v = t < tiles ? summary[t] : 0ull;
+    const PosSummary inc = wave_scan_summary(PosSummary{(u32)(v >> 32), (u32)v});
+    PosSummary excl;
+    excl.x = __shfl_up(inc.x, 1, 64);
+    excl.y = __shfl_up(inc.y, 1, 64);
+    if (lane == 0) excl.x = excl.y = 0;
+    if (t < tiles) summary[t] = ((u64)excl.x << 32) | excl.y;
+    u64 seen = 0;
+    if (lane == 63) {
+        const u64 old = atomicExch((unsigned long long*)&runSummary[blockIdx.x], ((u64)inc.x << 32) | inc.y);
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the exchange has been performed
+        // (the returned value is of no interest -- whatever the buffer held before -- but asking for it
+        // here keeps the exchange, and the wait for it, in front of the count-off)
+        asm volatile("" : : "v"((u32)old), "v"((u32)(old >> 32)) : "memory");
+        seen = atomicAdd((unsigned long long*)done, 1ull) + 1;
+    }
+    const u32 count = (u32)__builtin_amdgcn_readlane((u32)seen, 63);
+    if (count != gridDim.x) return;
+    // Last wave: 64 runs at a time, the runs in front carried along.
+    const u32 runs = gridDim.x;
+    const u64 p0 = 8ull * (u64)interval_marker_bytes(g, 0);
+    PosSummary before = {0u, 0u};
+    for (u32 first = 0; first < runs; first += 64) {
+        const u32 r = first + (u32)lane;
+        const u64 w = r < runs ? __hip_atomic_load(&runSummary[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        const PosSummary in = wave_scan_summary(PosSummary{(u32)(w >> 32), (u32)w});
+        PosSummary ex;
+        ex.x = __shfl_up(in.x, 1, 64);
+        ex.y = __shfl_up(in.y, 1, 64);
+        if (lane == 0) ex.x = ex.y = 0;
+        if (r < runs) runSummary[r] = pos_apply(pos_combine(before, ex), p0);
+        before = pos_combine(before, PosSummary{(u32)__builtin_amdgcn_readlane(in.x, 63), (u32)__builtin_amdgcn_readlane(in.y, 63)});
+    }
+}
+
 // Deferred placement (see k_encode_groups): one wave per tile; state[tile] holds the summary of the
 // tiles in front of it inside its run of 64, runStart the position at which the run starts
 // (k_group_positions, k_run_positions).
@@ -872,6 +932,15 @@ __global__ __launch_bounds__(256) void k_place_tiles(KGeom g, const u64* __restr
     const u32 h = whole.x & 0x7fffffffu;
     u64* edges = (u64*)(slot + kGrpSlotEdges);
     const u64 at = start + h;
+    // Nothing is written outside the stream's buffer, whatever the positions say: a tile whose
+    // part would end behind it reports a broken chain instead (the host then fails the call).
+    if (((at + 7) >> 3) + ((whole.x >> 31) ? ((u64)whole.y >> 3) + 1 : 0) + 8 > (u64)zeroedBytes) {
+        if (lane == 0) {
+            edges[0] = edges[1] = edges[2] = edges[3] = kNoEdge;
+            atomicOr((unsigned long long*)&result[1], 2ull);
+        }
+        return;
+    }
     const u32 padN = (whole.x >> 31) && g.padOnes ? (u32)(((at + 7) & ~7ull) - at) : 0u;
     slot_place(lo, h, start, words, edges, ffCount, at, padN);
     if ((whole.x >> 31) == 0) {

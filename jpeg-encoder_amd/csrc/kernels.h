@@ -84,11 +84,6 @@ struct EntropyWorkspace {
     // Room for the staged bits of the tiles of 256 blocks (group_slot_bytes), or null: the tiles
     // then chain with a look-back and place their bits themselves.
     uint32_t* tileSlots;
-    // Symbol records of the current coefficients (launch_symbol_records), or null: the bit
-    // writer then reads the coefficients themselves.
-    const uint32_t* records;
-    const uint32_t* recCount;        // the word launch_symbol_records flags overflow in, then one count per tile of 256 blocks
-    uint32_t recGeneration;
     const uint8_t* header;           // file header staged in device memory, copied to the front of the output
     int headerLen;                   // (0: none); prefixLen of launch_entropy covers it
     // Tables (uint32[4][256]) and, right behind them, headerLen header bytes in pinned host
@@ -144,15 +139,7 @@ hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, unsigned long
                             bool clear = true, HistogramExport* ex = nullptr);
 hipError_t launch_clear_histograms(unsigned long long* d_hist, int images, hipStream_t s);
 
-// Histograms and symbol records in one pass (single images of a few hundred thousand blocks and
-// more; records_path_takes says which).  d_records: records_tiles(g) slots of kRecordsPerTile
-// words; d_recCount: 1 + records_tiles(g) words, the first one zero before the first launch.
-constexpr int kRecordsPerTile = 6144;
-bool records_path_takes(const KGeom& g);
 long long group_slot_bytes(const KGeom& g);   // EntropyWorkspace::tileSlots
-long long records_tiles(const KGeom& g);
-hipError_t launch_symbol_records(const KGeom& g, const int16_t* d_coef, unsigned long long* d_hist, hipStream_t s, bool clear,
-                                 HistogramExport* ex, uint32_t* d_records, uint32_t* d_recCount, uint32_t generation);
 
 // Single-pass bit writer (lengths, positions, bits) and byte stuffing.  d_tables:
 // uint32[4][256], entry = (length << 16) | code.  Scan bytes go to d_out + prefixLen; EOI is appended when

@@ -28,7 +28,7 @@ EXPORTS = [
     "jpeg_hip_build_huffman", "jpeg_hip_get_huffman", "jpeg_hip_emit_scan", "jpeg_hip_emit_scan_host",
     "jpeg_hip_get_coefficients",
     "jpeg_hip_coefficients_device", "jpeg_hip_encode_sharded", "jpeg_hip_allreduce_histograms", "jpeg_hip_comm_unique_id", "jpeg_hip_comm_create", "jpeg_hip_comm_destroy", "jpeg_hip_analyze_band", "jpeg_hip_finish_band", "jpeg_hip_finish_band_start", "jpeg_hip_finish_band_wait", "jpeg_hip_set_profiling",
-    "jpeg_hip_get_timings", "jpeg_hip_decode_info", "jpeg_hip_decode", "jpeg_hip_decode_host",
+    "jpeg_hip_get_timings", "jpeg_hip_get_host_timeline", "jpeg_hip_get_profile_sums", "jpeg_hip_decode_info", "jpeg_hip_decode", "jpeg_hip_decode_host",
     "jpeg_hip_decoded_coefficients", "jpeg_hip_psnr", "jpeg_hip_synthetic_images", "jpeg_hip_filter_pixels", "jpeg_hip_get_pixels", "jpeg_hip_channel_gain",
 ]
 
@@ -137,6 +137,8 @@ def lib():
         L.jpeg_hip_synthetic_images.argtypes = [vp, i32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, vp, i64, i64, i32]
         L.jpeg_hip_set_profiling.argtypes = [vp, i32]
         L.jpeg_hip_get_timings.argtypes = [vp, vp]
+        L.jpeg_hip_get_host_timeline.argtypes = [vp, vp]
+        L.jpeg_hip_get_profile_sums.argtypes = [vp, vp, vp, C.POINTER(i64)]
         _lib = L
     return _lib
 
@@ -550,6 +552,18 @@ class Context:
         self._after_torch()
         self._check(lib().jpeg_hip_synthetic_images(self._h, {"noise": 0, "natural": 1}[kind], width, y0, y1,
                                                     seed & 0xFFFFFFFF, C.c_void_p(d_out), stride, image_stride, count))
+
+    def host_timeline(self):
+        """Host clock (microseconds) at the eight stations of the last analyze / finish pair."""
+        t = np.zeros(8, np.float64)
+        self._check(lib().jpeg_hip_get_host_timeline(self._h, _np(t)))
+        return t
+
+    def profile_sums(self):
+        """(stage_ms[4], host_us[8], images) added up since set_profiling(True)."""
+        ms, us, n = np.zeros(4, np.float64), np.zeros(8, np.float64), C.c_int64(0)
+        self._check(lib().jpeg_hip_get_profile_sums(self._h, _np(ms), _np(us), C.byref(n)))
+        return ms, us, n.value
 
     def timings(self):
         t = np.zeros(4, np.float32)

@@ -142,26 +142,6 @@ def test_bands_concatenate_to_the_whole_file(ctx):
     assert b"".join(pieces) == whole
 
 
-@pytest.mark.parametrize("scheme", ["444", "420", "411"])
-def test_two_pass_form_with_symbol_records(ctx, scheme):
-    """Histograms and symbol records in one pass, bits from the records (opt-in, JPEGENC_RECORDS=1):
-    the same files as the oracle's, with and without restart intervals, one-bit padding, a
-    slot too small for its tile (noise at q=100: the bit writer then codes from the coefficients)."""
-    _tile(None)
-    os.environ["JPEGENC_RECORDS"] = "1"
-    try:
-        for (w, h, kind, tname, ri, pad) in [(640, 360, "natural", "annexk", 0, False), (333, 77, "noise", "annexk", 0, False),
-                                             (331, 203, "noise", "ps12", 8, True), (331, 203, "natural", "ps12", 40, False),
-                                             (512, 256, "noise", "ones", 0, False), (9, 500, "noise", "annexk", 1000, True)]:
-            img = synth.generate(kind, w, h, seed=w + h)
-            qt = T.NAMED_TABLES[tname]
-            enc = O.encode(img, T.SCHEMES[scheme], qt, restart_interval=ri, pad_ones=pad)
-            prm = B.make_params(w, h, T.SCHEMES[scheme], qt, restart_interval=ri, pad_ones=pad)
-            assert ctx.encode_host(img, prm) == enc.jpeg, (scheme, w, h, kind, tname, ri, pad)
-    finally:
-        os.environ.pop("JPEGENC_RECORDS", None)
-
-
 def test_tiles_that_chain_with_a_look_back(ctx):
     """The other way to place a tile's bits (the tile waits for its start and writes them itself),
     which small images and the smaller tiles take."""
