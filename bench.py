@@ -38,6 +38,12 @@ WORKLOADS = {
     "8k_noise_q100_444": (8192, 8192, "444", 100, "noise", "8192x8192 uniform noise, 4:4:4, q=100 (all-ones tables)"),
     "8k_noise_q100_420": (8192, 8192, "420", 100, "noise", "8192x8192 uniform noise, 4:2:0, q=100 (all-ones tables)"),
     "1080p_420_q90": (1920, 1080, "420", 90, "natural", "1920x1080 synthetic natural-like RGB8, 4:2:0, q=90"),
+    # the middle of the density range (about 200 bits per block), between photographic content and the noise at q=100
+    "4k2_noise_q75_444": (4096, 4096, "444", 75, "noise", "4096x4096 uniform noise, 4:4:4, q=75"),
+    "4k2_noise_q75_420": (4096, 4096, "420", 75, "noise", "4096x4096 uniform noise, 4:2:0, q=75"),
+    "4k2_mixed_q90_420": (4096, 4096, "420", 90, "mixed", "4096x4096 natural-like with a band of uniform noise (a 128th of the rows), 4:2:0, q=90"),
+    "4k2_noise_q50_420": (4096, 4096, "420", 50, "noise", "4096x4096 uniform noise, 4:2:0, q=50"),
+    "4k2_noise_q90_420": (4096, 4096, "420", 90, "noise", "4096x4096 uniform noise, 4:2:0, q=90"),
     "batch_1080p_420_q90": (1920, 1080, "420", 90, "natural",
                             "batch of 1920x1080 synthetic natural-like RGB8 frames (different seeds), 4:2:0, q=90, "
                             "one call per step, frames split evenly over the ranks (throughput mode)"),
@@ -301,12 +307,21 @@ def main():
         ctx.synthetic_images(kind, width, 0, height, 1000 + rank * batch, rgb.data_ptr(), stride, image_stride, batch)
     else:
         rgb = torch.empty((y1 - y0) * stride, dtype=torch.uint8, device=dev)
-        ctx.synthetic_images(kind, width, y0, y1, 42 if kind == "noise" else 1, rgb.data_ptr(), stride)
+        if kind == "mixed":
+            # natural content with a narrow band of uniform noise across the middle (a 128th of the rows):
+            # the histograms of the whole image say "photographic", one tile in 128 is as dense as noise
+            ctx.synthetic_images("natural", width, y0, y1, 1, rgb.data_ptr(), stride)
+            b0, b1 = synth.mixed_band(height)
+            n0, n1 = max(y0, b0), min(y1, b1)
+            if n1 > n0:
+                ctx.synthetic_images("noise", width, n0, n1, 42, rgb.data_ptr() + (n0 - y0) * stride, stride)
+        else:
+            ctx.synthetic_images(kind, width, y0, y1, 42 if kind == "noise" else 1, rgb.data_ptr(), stride)
     hist = torch.zeros((4, 256), dtype=torch.int64, device=dev)
     # Output capacity: the worst case bound is huge; 1.5 bytes per pixel of the band plus
     # slack covers every workload here (noise at q=100 needs about 1.1 B/px in 4:2:0 and
     # 2.9 B/px in 4:4:4, which gets its own bound).
-    per_px = 3.2 if kind == "noise" else (0.5 if args.standard_huffman else 1.0)
+    per_px = 3.2 if kind in ("noise", "mixed") else (0.5 if args.standard_huffman else 1.0)
     cap = int((y1 - y0 + lay.mcu_height) * lay.padded_width * per_px) + (1 << 20)
     out = torch.empty(cap * max(batch, 1), dtype=torch.uint8, device=dev)
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
@@ -424,6 +439,7 @@ def main():
     sync()
     kern_ms = np.zeros(4)
     host_tl = np.zeros(8)
+    entropy_runs = [0, 0]       # launches of the entropy stage, images (equal unless a bit writer had to be run again)
     for lane in lanes:
         lane[0].set_profiling(True)      # clears the sums the library keeps per context
     t0 = time.perf_counter()
@@ -432,9 +448,11 @@ def main():
     elapsed = time.perf_counter() - t0
     if not batch:       # single images: the library has added up stage times and host stations itself
         for lane in lanes:
-            ms, us, _ = lane[0].profile_sums()
+            ms, us, imgs, runs = lane[0].profile_sums()
             kern_ms += ms
             host_tl += us
+            entropy_runs[0] += runs
+            entropy_runs[1] += imgs
     own_elapsed = elapsed
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -489,6 +507,7 @@ def main():
             "roofline_stages": stage_rooflines(lay, max(batch, 1), int(n_out), kern_ms),
             "stage_ms": {"transform": round(float(kern_ms[0]), 4), "histogram": round(float(kern_ms[1]), 4),
                          "entropy": round(float(kern_ms[2]), 4), "host_tables": round(float(kern_ms[3]), 4)},
+            "entropy_stage_runs_per_image": round(entropy_runs[0] / entropy_runs[1], 3) if entropy_runs[1] else None,
             "per_rank": per_rank,
         }
         if not args.no_cpu_baseline and world == 1:

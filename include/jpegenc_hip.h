@@ -381,9 +381,12 @@ int jpeg_hip_get_host_timeline(jpeg_hip_ctx* ctx, double out_us[8]);
 /* The same figures added up over the single images encoded since jpeg_hip_set_profiling(ctx, 1)
  * was last called (which clears the sums): stage_ms as jpeg_hip_get_timings, host_us[0..6] the
  * seven intervals between the stations of jpeg_hip_get_host_timeline, host_us[7] the time from
- * one image's result to the next image's entry, *images the number of images.  For loops in
- * which asking after every image would cost more than the answer is worth. */
-int jpeg_hip_get_profile_sums(jpeg_hip_ctx* ctx, double stage_ms[4], double host_us[8], int64_t* images);
+ * one image's result to the next image's entry, *images the number of images, *entropy_runs
+ * the number of times the entropy stage was launched for them (one per image unless a bit writer
+ * had to be run again in another form).  For loops in which asking after every image would cost
+ * more than the answer is worth. */
+int jpeg_hip_get_profile_sums(jpeg_hip_ctx* ctx, double stage_ms[4], double host_us[8], int64_t* images,
+                              int64_t* entropy_runs);
 
 /* ---- verification decoder ---------------------------------------------------------------- */
 

@@ -354,6 +354,32 @@ int group_tile_for(int64_t avgBlockBits) {
     return 0;
 }
 
+// The same from what the histogram pass saw of the image's densest tiles (HistogramExport::hostStats),
+// so that the form that fits is taken at once instead of being found by running the stage again:
+// the image's mean says nothing about a band of dense texture in an otherwise smooth picture.
+// A tile's bits are estimated as its symbols (non-zero AC coefficients, a DC term and an end of
+// block per block) times the image's mean bits per symbol, plus a margin for symbols that are
+// rarer -- and so longer -- in the dense places than on average.  Dense tiles go to the
+// one-lane-per-block writer, not to tiles of 16 blocks (4096 x 4096 with a band of noise: 95 against 143 us).
+int group_tile_from_stats(const jpeg_hip_ctx* ctx, int64_t streamBits, const uint64_t* hist) {
+    if (const char* forced = getenv("JPEGENC_GROUP_TILE")) return atoi(forced);
+    uint64_t symbols = 0;
+    for (int i = 0; i < 1024; ++i) symbols += hist[i];
+    if (symbols == 0 || streamBits <= 0) return 256;
+    const double bitsPerSymbol = (double)streamBits / (double)symbols;
+    const double room = 0.97 * 22528.0;   // kGrpStageBits, less the slack the kernel keeps behind a lane's bits
+    const uint64_t items = ctx->pin->tileStats[0], nz256 = ctx->pin->tileStats[1], nz64 = ctx->pin->tileStats[2];
+    // (interval ends are items too: at most one per 16 blocks)
+    const bool list256 = items + 16 <= 1278;   // kGrpMaxItems
+    // Margins: a quarter more for the large tiles; half as much again for the small ones, which
+    // are chosen when the large ones do not fit, i.e. for the dense places themselves (measured: the
+    // band of noise in a smooth image costs 6.2 bits per symbol where the image's mean is 4.5), and
+    // lose nothing to the one-lane-per-block writer on dense content anyway.
+    if (list256 && (double)(nz256 + 2 * 256) * bitsPerSymbol * 1.25 <= room) return 256;
+    if ((double)(nz64 + 2 * 64) * bitsPerSymbol * 1.5 <= room) return 64;
+    return 0;
+}
+
 int launch_entropy_kernels(jpeg_hip_ctx* ctx) {
     // Padding (< 1 byte) and a marker per interval on top of the coded bits, EOI, slack.
     // Without histograms the output capacity bounds the stream: a longer one fails anyway.
@@ -366,6 +392,7 @@ int launch_entropy_kernels(jpeg_hip_ctx* ctx) {
     // The kernels write length and error flags into the pinned record themselves.
     ctx->pin->result[0] = ctx->pin->result[1] = ctx->pin->result[2] = ctx->pin->result[3] = 0;
     ctx->ws.hostResult = (unsigned long long*)ctx->pin->result;
+    ++ctx->sumEntropyRuns;
     HIP_TRY(ctx, launch_entropy(ctx->kg, (const int16_t*)ctx->coef.p, (const uint32_t*)ctx->tables.p, ctx->ws, ctx->emitOut,
                                 prefix, capacity, ctx->kg.writeEoi, ctx->stream));
     return JPEG_HIP_OK;
@@ -376,7 +403,8 @@ int run_entropy_launch(jpeg_hip_ctx* ctx, uint8_t* d_out, int64_t prefix, int64_
     ctx->kg.writeEoi = writeEoi;
     // The histograms (and so streamBits) cover the whole image even when this context encodes a band.
     ctx->ws.avgBlockBits = ctx->streamBits < 0 ? -1 : ctx->streamBits / ((int64_t)ctx->geo.mcuRows * ctx->geo.mcusPerRow * ctx->geo.blocksPerMcu);
-    ctx->ws.groupTile = group_tile_for(ctx->ws.avgBlockBits);
+    ctx->ws.groupTile = ctx->tileStatsValid && ctx->streamBits >= 0 ? group_tile_from_stats(ctx, ctx->streamBits, ctx->pin->hist)
+                                                                    : group_tile_for(ctx->ws.avgBlockBits);
     ctx->ws.tileSlots = nullptr;
     // Deferred placement of the tiles' bits pays for large images (16384 x 16384: 363 -> 315 us for
     // the stage, 3840 x 2160: 49 -> 50).  (Diagnostic switch JPEGENC_SLOTS_MIN_BLOCKS: another threshold.)
@@ -427,7 +455,7 @@ int run_entropy_wait(jpeg_hip_ctx* ctx, int64_t* outLen) {
     // the stage again with a full clear / with smaller tiles.
     for (int attempt = 0; attempt < 5 && (ctx->pin->result[3] & (4 | 8)) != 0 && (ctx->pin->result[3] & (2 | 16)) == 0; ++attempt) {
         if (ctx->pin->result[3] & 4) ctx->streamBits = -1;
-        if (ctx->pin->result[3] & 8) ctx->ws.groupTile = ctx->ws.groupTile > 64 ? 64 : (ctx->ws.groupTile > 16 ? 16 : 0);
+        if (ctx->pin->result[3] & 8) ctx->ws.groupTile = ctx->ws.groupTile > 64 ? 64 : 0;   // (tiles of 16 blocks lose to the one-lane-per-block writer on dense content)
         ctx->ws.pendingTables = nullptr;   // tables and header are on the device by now
         const int st = launch_entropy_kernels(ctx);
         if (st != JPEG_HIP_OK) return st;
@@ -503,6 +531,7 @@ int do_transform(jpeg_hip_ctx* ctx, int stages, bool staged = false, uint64_t* c
                                   ctx->stream, (unsigned long long*)clearHist));
     mark(ctx, 1);
     ctx->transformed = true;
+    ctx->tileStatsValid = ctx->tileStatsPending = false;
     ctx->stagedScanLen = -1;
     // Whatever histograms the installed tables came from, they did not count these
     // coefficients: the bit count derived from them bounds nothing any more.
@@ -515,19 +544,25 @@ int do_transform(jpeg_hip_ctx* ctx, int stages, bool staged = false, uint64_t* c
 int do_histograms(jpeg_hip_ctx* ctx, uint64_t* d_hist, bool cleared = false, bool toHost = false) {
     if (!ctx->transformed) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "histograms need the transform");
     ctx->histOnHost = false;
-    HistogramExport ex = {nullptr, 0, nullptr};
+    HistogramExport ex = {nullptr, 0, nullptr, nullptr, nullptr};
     if (toHost) {
-        if (!ctx->histDone.p) {   // the workgroups' counter starts at zero and is never reset
-            HIP_TRY(ctx, ctx->histDone.ensure(8));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->histDone.p, 0, 8, ctx->stream));
+        if (!ctx->histDone.p) {   // the workgroups' counter starts at zero and is never reset; behind it a word per workgroup for the tile statistics
+            HIP_TRY(ctx, ctx->histDone.ensure(64 + 8 * kHistogramMaxGrid));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->histDone.p, 0, 64, ctx->stream));
             ctx->histExpected = 0;
         }
         ex.counter = (unsigned long long*)ctx->histDone.p;
         ex.expected = ctx->histExpected;
         ex.host = (unsigned long long*)ctx->pin->hist;
+        // (Diagnostic switch JPEGENC_TILE_STATS=0: the pass keeps no statistics and the bit writer's form follows the mean block length.)
+        static const bool noStats = getenv("JPEGENC_TILE_STATS") != nullptr && getenv("JPEGENC_TILE_STATS")[0] == '0';
+        ex.stats = noStats ? nullptr : (unsigned long long*)ctx->histDone.p + 8;
+        ex.hostStats = (unsigned long long*)ctx->pin->tileStats;
     }
     HIP_TRY(ctx, launch_histogram(ctx->kg, (const int16_t*)ctx->coef.p, (unsigned long long*)d_hist, ctx->stream, !cleared,
                                   toHost ? &ex : nullptr));
+    ctx->tileStatsValid = false;
+    ctx->tileStatsPending = toHost;   // the kernel leaves them in the pinned block
     if (toHost) {
         ctx->histExpected = ex.expected;
         ctx->histOnHost = true;
@@ -543,12 +578,15 @@ int fetch_hist_and_build(jpeg_hip_ctx* ctx, const uint64_t* d_hist, int64_t capa
         if (!ctx->histOnHost) return fail(ctx, JPEG_HIP_ERR_BAD_STATE, "no histograms of this band: pass the summed ones");
         HIP_TRY(ctx, wait_stream(ctx));
         tick(ctx, 3);
+        ctx->tileStatsValid = ctx->pin->tileStats[3] == 1;
         return build_tables(ctx, ctx->pin->hist, true, capacity, headerLen);
     }
     ctx->histOnHost = false;   // the pinned block is about to hold the caller's histograms
     HIP_TRY(ctx, hipMemcpyAsync(ctx->pin->hist, d_hist, sizeof ctx->pin->hist, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, wait_stream(ctx));
     tick(ctx, 3);
+    // (the statistics are the band's own even when the histograms are the whole image's)
+    ctx->tileStatsValid = ctx->tileStatsPending && ctx->pin->tileStats[3] == 1;
     return build_tables(ctx, ctx->pin->hist, true, capacity, headerLen);
 }
 
@@ -1131,6 +1169,7 @@ int jpeg_hip_set_profiling(jpeg_hip_ctx* ctx, int enabled) {
     for (auto& v : ctx->sumTimes) v = 0;
     for (auto& v : ctx->sumTimeline) v = 0;
     ctx->sumCount = 0;
+    ctx->sumEntropyRuns = 0;
     ctx->lastResultSeen = 0;
     return JPEG_HIP_OK;
 }
@@ -1141,8 +1180,9 @@ int jpeg_hip_get_host_timeline(jpeg_hip_ctx* ctx, double out_us[8]) {
     return JPEG_HIP_OK;
 }
 
-int jpeg_hip_get_profile_sums(jpeg_hip_ctx* ctx, double stage_ms[4], double host_us[8], int64_t* images) {
-    if (!ctx || !stage_ms || !host_us || !images) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+int jpeg_hip_get_profile_sums(jpeg_hip_ctx* ctx, double stage_ms[4], double host_us[8], int64_t* images, int64_t* entropy_runs) {
+    if (!ctx || !stage_ms || !host_us || !images || !entropy_runs) return JPEG_HIP_ERR_INVALID_ARGUMENT;
+    *entropy_runs = ctx->sumEntropyRuns;
     memcpy(stage_ms, ctx->sumTimes, sizeof ctx->sumTimes);
     memcpy(host_us, ctx->sumTimeline, sizeof ctx->sumTimeline);
     *images = ctx->sumCount;
@@ -1459,7 +1499,7 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
             const uint64_t flags = h.off[2 * (h.cnt + 1) + 1];
             if ((flags & (4 | 8)) == 0 || (flags & (2 | 16)) != 0) break;
             if (flags & 4) h.ws.streamBound = -1;
-            if (flags & 8) h.ws.groupTile = h.ws.groupTile > 64 ? 64 : (h.ws.groupTile > 16 ? 16 : 0);
+            if (flags & 8) h.ws.groupTile = h.ws.groupTile > 64 ? 64 : 0;
             const int st = launch_batch_half(ctx, h);
             if (st != JPEG_HIP_OK) return st;
             HIP_TRY(ctx, wait_stream(ctx));

@@ -84,6 +84,7 @@ struct Pinned {
     uint8_t header[kHeaderCapacity];
     uint64_t result[4];
     uint64_t exchangeFlag;              // failure flags of a sharded encode, to and from the device
+    uint64_t tileStats[4];              // HistogramExport::hostStats of the last histogram pass
 };
 
 // Host threads that stay around between batch passes: starting sixteen threads costs more
@@ -233,6 +234,8 @@ struct jpeg_hip_ctx {
     jpeghip::DevBuf histDone;                             // counter of the histogram kernel's host export
     unsigned long long histExpected = 0;         // value of that counter once every launch so far has finished
     bool histOnHost = false;                     // pin->hist holds the current band's histograms as counted
+    bool tileStatsPending = false;               // the histogram pass in flight (or done) leaves pin->tileStats
+    bool tileStatsValid = false;                 // pin->tileStats describe the current coefficients and have arrived
     bool tablesPending = false;                  // pin->tables (+ pendingHeaderLen header bytes) are not on the device yet
     int pendingHeaderLen = 0;
     int nGains = 0;                              // jpeg_hip_channel_gain calls since begin()
@@ -260,6 +263,7 @@ struct jpeg_hip_ctx {
     double sumTimeline[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // ... the seven intervals of hostTimeline, and the gap between images
     double lastResultSeen = 0;                           // hostTimeline[7] of the image before
     int64_t sumCount = 0;
+    int64_t sumEntropyRuns = 0;                          // launches of the entropy stage (more than sumCount: some images needed a second run)
 };
 
 #endif

@@ -151,7 +151,9 @@ struct HistVisitor {
 
 // Adds a workgroup's 1024 counters in LDS (complete: the caller has passed a barrier) to the
 // image's histograms in memory, and hands the sums to the host when the export asks for it.
-__device__ __forceinline__ void flush_histograms(u32* lh, u64* __restrict__ hist, const HistogramExport& ex) {
+// tileStats (may be null): the workgroup's three maxima for HistogramExport::stats.
+__device__ __forceinline__ void flush_histograms(u32* lh, u64* __restrict__ hist, const HistogramExport& ex,
+                                                 const u32* tileStats = nullptr) {
     __shared__ bool lastOne;
     u64* mine = hist + (long long)blockIdx.y * 1024;
     if (ex.host == nullptr) {
@@ -171,6 +173,12 @@ __device__ __forceinline__ void flush_histograms(u32* lh, u64* __restrict__ hist
         old[k] = v != 0 ? atomicAdd(&mine[k * kEntThreads + threadIdx.x], (u64)v) : 0;
     }
     u64 seen = 0;
+    // Tile statistics: one word per workgroup, put down with an exchange that returns like the additions
+    // above (three words for all to raise, one behind the other, cost a 22 us kernel of 285 workgroups 4 us).
+    u64 before = 0;   // (what the word held is of no interest; asking for it makes the exchange one that is waited for below)
+    if (tileStats != nullptr && ex.stats != nullptr && threadIdx.x == 0)
+        before = atomicExch((unsigned long long*)&ex.stats[blockIdx.x],
+                            ((u64)tileStats[0] << 40) | ((u64)tileStats[1] << 20) | (u64)tileStats[2]);
 #pragma unroll
     for (int k = 0; k < 1024 / kEntThreads; ++k) seen |= old[k];
     // The returned values have to be here before the workgroup counts itself off: an explicit wait
@@ -178,6 +186,7 @@ __device__ __forceinline__ void flush_histograms(u32* lh, u64* __restrict__ hist
     // store depends (under a condition that never holds), so that the compiler cannot move the
     // additions behind the barrier either.
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+    asm volatile("" : : "v"((u32)before), "v"((u32)(before >> 32)) : "memory");
     if (seen == ~0ull) lh[0] = 0;
     __syncthreads();
     if (threadIdx.x == 0) lastOne = atomicAdd(ex.counter, 1ull) + 1 == ex.expected;
@@ -185,6 +194,28 @@ __device__ __forceinline__ void flush_histograms(u32* lh, u64* __restrict__ hist
     if (!lastOne) return;
     for (int i = threadIdx.x; i < 1024; i += kEntThreads)
         ex.host[i] = __hip_atomic_load(&hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ex.hostStats != nullptr) {
+        // [3]: whether the kernel keeps these statistics at all
+        if (tileStats == nullptr || ex.stats == nullptr) {
+            if (threadIdx.x < 4) ex.hostStats[threadIdx.x] = 0;
+            return;
+        }
+        if (threadIdx.x >= 64) return;   // one wave gathers the workgroups' words
+        u32 a = 0, b = 0, c = 0;
+        for (u32 i = threadIdx.x; i < gridDim.x; i += 64) {
+            const u64 v = __hip_atomic_load(&ex.stats[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a = max(a, (u32)(v >> 40));
+            b = max(b, (u32)(v >> 20) & 0xfffffu);
+            c = max(c, (u32)v & 0xfffffu);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            a = max(a, (u32)__shfl_xor((int)a, d, 64));
+            b = max(b, (u32)__shfl_xor((int)b, d, 64));
+            c = max(c, (u32)__shfl_xor((int)c, d, 64));
+        }
+        if (threadIdx.x < 4) ex.hostStats[threadIdx.x] = threadIdx.x == 0 ? a : (threadIdx.x == 1 ? b : (threadIdx.x == 2 ? c : 1ull));
+    }
 }
 
 // blockIdx.y is the image of the batch; a workgroup never mixes images, so its LDS counts
@@ -247,7 +278,7 @@ hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, u64* d_hist, 
     const long long rounds = (passes + cap - 1) / cap;
     long long grid = (passes + rounds - 1) / rounds;
     if (grid < 1) grid = 1;
-    HistogramExport none = {nullptr, 0, nullptr};
+    HistogramExport none = {nullptr, 0, nullptr, nullptr, nullptr};
     // Large images: one lane per group of eight coefficients that is not empty (k_histogram_tiles).
     // (Diagnostic switch JPEGENC_HIST_FORM=1: always one lane per block.)
     static const bool perBlock = getenv("JPEGENC_HIST_FORM") != nullptr && getenv("JPEGENC_HIST_FORM")[0] == '1';
@@ -691,7 +722,10 @@ __device__ __forceinline__ bool look_back(const u64* state, long long tile, u64 
 // test can set it.)
 static long long histogram_tiles_min_blocks() {
     const char* env = getenv("JPEGENC_HIST_TILES_MIN_BLOCKS");
-    return env ? atoll(env) : 250000;
+    // (From where the bit writer on groups takes over, kGrpMinBlocks, although the pass itself only wins from a quarter
+    // of a million blocks on -- 197 k blocks: 21 against 20 us: the bit writer chooses its tile size by the
+    // statistics this pass keeps of the densest tiles.)
+    return env ? atoll(env) : 150000;
 }
 
 static hipError_t launch_histogram_tiles(const KGeom& g, const int16_t* d_coef, u64* d_hist, hipStream_t s, HistogramExport* ex) {
@@ -706,10 +740,11 @@ static hipError_t launch_histogram_tiles(const KGeom& g, const int16_t* d_coef, 
     // 8192 x 8192 4:2:0, 1536 workgroups, 102 -> 99 us).  Beyond that, giving every workgroup the same number
     // of turns was measured and is worse than the plain cap (16384 x 16384: 1229 workgroups 153 us, 1280: 141).
     if (grid > cap && !(g.batch == 1 && grid <= 1536)) grid = cap;
-    HistogramExport none = {nullptr, 0, nullptr};
+    HistogramExport none = {nullptr, 0, nullptr, nullptr, nullptr};
     if (ex != nullptr) ex->expected += (unsigned long long)grid;
-    hipLaunchKernelGGL(k_histogram_tiles<4>, dim3((unsigned)grid, (unsigned)g.batch), dim3(256), 0, s, g, d_coef, d_hist,
-                       ex != nullptr ? *ex : none);
+    HistogramExport given = ex != nullptr ? *ex : none;
+    if (grid > kHistogramMaxGrid) given.stats = nullptr;   // (no room for a word per workgroup: no tile statistics)
+    hipLaunchKernelGGL(k_histogram_tiles<4>, dim3((unsigned)grid, (unsigned)g.batch), dim3(256), 0, s, g, d_coef, d_hist, given);
     return hipGetLastError();
 }
 

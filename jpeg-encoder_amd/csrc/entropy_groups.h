@@ -282,10 +282,13 @@ __global__ __launch_bounds__(256) void k_histogram_tiles(KGeom g, const int16_t*
     u32* lh = (u32*)&items[0][0];   // at the end: the sums, laid out as flush_histograms expects them (DC-Y, DC-C, AC-Y, AC-C)
     static_assert(sizeof(items) >= 4 * 256 * sizeof(u32), "the sums take the lists' place");
     __shared__ unsigned char roleTab[4][kGrpTileBlocks];
+    __shared__ u32 tileStats[4];   // most items in a tile, most non-zero AC coefficients in a tile, in a quarter of a tile
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < (2 * 256 + 2 * 16) * kHistCopies; i += 256) cnt[i] = 0;
+    if (threadIdx.x < 4) tileStats[threadIdx.x] = 0;
     __syncthreads();
+    const bool wantStats = ex.stats != nullptr;
     u32* mine = cnt + (lane & (kHistCopies - 1));
     const u32 image = blockIdx.y;
     const u32 tiles = ((u32)g.blocksPerImage + kHistTileBlocks - 1) / kHistTileBlocks;
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(256) void k_histogram_tiles(KGeom g, const int16_t*
         t.tooMany = false;
         group_index_tile<false>(g, t);
         u32 carryVal = ~0u;
+        u64 nzQuarters = 0;   // non-zero coefficients the lane has met in the four quarters of the tile, 16 bits each
         GroupLoad ld;
         group_issue_loads<true>(t, 0, ld);
         for (int first = 0; first < t.nItems; first += 64) {
@@ -315,6 +319,8 @@ __global__ __launch_bounds__(256) void k_histogram_tiles(KGeom g, const int16_t*
             const int n = t.nItems - first < 64 ? t.nItems - first : 64;
             carryVal = __builtin_amdgcn_readlane(f.val, n - 1);
             group_issue_loads<true>(t, first + 64, ld);   // the next chunk's groups arrive while this one is counted
+            if (wantStats)   // (idle lanes repeat the tile's last item with all flags clear; group 0's forced flag is taken off below)
+                nzQuarters += (u64)(u32)__popc(f.mm & 0xffu) << ((f.lb >> 2) & 48u);
             u32* ac = mine + f.chroma * (256 * kHistCopies);
             if (f.zr != 0) atomicAdd(&ac[0xF0 * kHistCopies], (u32)f.zr);          // Encoder.cpp:318-328
             if (f.needEob) atomicAdd(&ac[0], 1u);                                  // Encoder.cpp:343-347
@@ -328,6 +334,23 @@ __global__ __launch_bounds__(256) void k_histogram_tiles(KGeom g, const int16_t*
                     const u32 run = (u32)__builtin_clz(f.X << (16 - j)) & 15u;
                     atomicAdd(&ac[((run << 4) | cat) * kHistCopies], 1u);
                 }
+            }
+        }
+        if (wantStats) {
+            // A quarter of a tile has at most 64 * 64 of them: the sums of two quarters travel in one register.
+            const u32 lo = (u32)__builtin_amdgcn_readlane(wave_scan_add((u32)nzQuarters), 63);
+            const u32 hi = (u32)__builtin_amdgcn_readlane(wave_scan_add((u32)(nzQuarters >> 32)), 63);
+            // Every block's group 0 counted its DC term as well: a quarter has 64 blocks (the image's last tile fewer).
+            auto ac = [&](u32 sum, int quarter) {
+                const int blocks = t.nBlocks - 64 * quarter;
+                const u32 dc = (u32)(blocks < 0 ? 0 : (blocks > 64 ? 64 : blocks));
+                return sum > dc ? sum - dc : 0u;
+            };
+            const u32 q0 = ac(lo & 0xffffu, 0), q1 = ac(lo >> 16, 1), q2 = ac(hi & 0xffffu, 2), q3 = ac(hi >> 16, 3);
+            if (lane == 0) {
+                atomicMax(&tileStats[0], (u32)t.nItems);
+                atomicMax(&tileStats[1], q0 + q1 + q2 + q3);
+                atomicMax(&tileStats[2], max(max(q0, q1), max(q2, q3)));
             }
         }
         // The list is this wave's own: the wave's next tile may overwrite it once the wave is here.
@@ -344,7 +367,7 @@ __global__ __launch_bounds__(256) void k_histogram_tiles(KGeom g, const int16_t*
         lh[i] = v;
     }
     __syncthreads();
-    flush_histograms(lh, hist, ex);
+    flush_histograms(lh, hist, ex, tileStats);
 }
 
 // ---- bit writer -----------------------------------------------------------------------------

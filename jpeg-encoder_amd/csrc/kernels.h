@@ -130,10 +130,18 @@ hipError_t launch_interleave_planes(const float* d_planes, long long planeFloats
 // ex (single images only): the kernel also writes the finished histograms to ex->host, pinned
 // host memory, so that the host needs no copy; ex->counter is a device word the workgroups
 // count themselves off with, never reset, and ex->expected follows it from launch to launch.
+constexpr int kHistogramMaxGrid = 2048;
 struct HistogramExport {
     unsigned long long* counter;
     unsigned long long expected;
     unsigned long long* host;
+    // Density of the image's densest tiles, for the choice of the bit writer (k_histogram_tiles
+    // only; k_histogram leaves hostStats[3] at 0): stats is device memory, one word per workgroup
+    // of the launch (kHistogramMaxGrid at most); hostStats (pinned) receives [0] the most non-empty groups in a
+    // tile of 256 blocks, [1] the most non-zero AC coefficients in such a tile, [2] the most in a
+    // run of 64 blocks (a quarter of a tile), [3] 1.  Both null: not wanted.
+    unsigned long long* stats;
+    unsigned long long* hostStats;
 };
 hipError_t launch_histogram(const KGeom& g, const int16_t* d_coef, unsigned long long* d_hist, hipStream_t s,
                             bool clear = true, HistogramExport* ex = nullptr);

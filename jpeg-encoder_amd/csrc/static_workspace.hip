@@ -117,7 +117,7 @@ int jpeg_hip_encode_static(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_form
     // the 0xFF counts that go with it, 4 bytes per 4 KiB chunk and 8 per 64 chunks) gets the rest.
     const WorkspaceSizes fixed = workspace_sizes(g, 1, 0);
     const size_t fixedBytes = round256(fixed.coef) + round256(fixed.gmask) + round256(fixed.qtab) + round256(fixed.hist) + round256(fixed.tables) +
-                              round256(fixed.ivOff) + round256(fixed.result) + round256(fixed.tileState) + 256 /* histDone */;
+                              round256(fixed.ivOff) + round256(fixed.result) + round256(fixed.tileState) + round256(64 + 8 * kHistogramMaxGrid) /* histDone */;
     const size_t margin = 64u << 10;   // rounding of the slices, the counts of a partial chunk
     if (fixedBytes + margin + (1u << 20) > kStaticWorkspaceBytes)
         return fail(ctx, JPEG_HIP_ERR_BUFFER_TOO_SMALL,
@@ -152,7 +152,7 @@ int jpeg_hip_encode_static(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_form
         loan.lend(ctx->ivOff, cursor, sz.ivOff);
         loan.lend(ctx->result, cursor, sz.result);
         loan.lend(ctx->tileState, cursor, sz.tileState);
-        loan.lend(ctx->histDone, cursor, 8);
+        loan.lend(ctx->histDone, cursor, 64 + 8 * kHistogramMaxGrid);
         loan.lend(ctx->ffCount, cursor, sz.ffCount);
         loan.lend(ctx->groupSum, cursor, sz.groupSum);
         loan.lend(ctx->unstuffed, cursor, sz.unstuffed);
@@ -165,7 +165,7 @@ int jpeg_hip_encode_static(jpeg_hip_ctx* ctx, const void* d_rgb, int sample_form
             // start at zero (the histograms, tile states, result record and the stream's reachable
             // part are cleared by the kernels that use them).
             ctx->histExpected = 0;
-            he = hipMemsetAsync(ctx->histDone.p, 0, 8, ctx->stream);
+            he = hipMemsetAsync(ctx->histDone.p, 0, 64, ctx->stream);
             if (he != hipSuccess) {
                 st = fail(ctx, JPEG_HIP_ERR_HIP, "clearing the static workspace failed");
             } else {

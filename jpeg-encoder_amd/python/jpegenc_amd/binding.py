@@ -138,7 +138,7 @@ def lib():
         L.jpeg_hip_set_profiling.argtypes = [vp, i32]
         L.jpeg_hip_get_timings.argtypes = [vp, vp]
         L.jpeg_hip_get_host_timeline.argtypes = [vp, vp]
-        L.jpeg_hip_get_profile_sums.argtypes = [vp, vp, vp, C.POINTER(i64)]
+        L.jpeg_hip_get_profile_sums.argtypes = [vp, vp, vp, C.POINTER(i64), C.POINTER(i64)]
         _lib = L
     return _lib
 
@@ -560,10 +560,10 @@ class Context:
         return t
 
     def profile_sums(self):
-        """(stage_ms[4], host_us[8], images) added up since set_profiling(True)."""
-        ms, us, n = np.zeros(4, np.float64), np.zeros(8, np.float64), C.c_int64(0)
-        self._check(lib().jpeg_hip_get_profile_sums(self._h, _np(ms), _np(us), C.byref(n)))
-        return ms, us, n.value
+        """(stage_ms[4], host_us[8], images, entropy stage launches) added up since set_profiling(True)."""
+        ms, us, n, runs = np.zeros(4, np.float64), np.zeros(8, np.float64), C.c_int64(0), C.c_int64(0)
+        self._check(lib().jpeg_hip_get_profile_sums(self._h, _np(ms), _np(us), C.byref(n), C.byref(runs)))
+        return ms, us, n.value, runs.value
 
     def timings(self):
         t = np.zeros(4, np.float32)

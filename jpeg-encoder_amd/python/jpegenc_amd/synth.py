@@ -47,8 +47,22 @@ def natural(width, height, seed=1, y0=0, y1=None, full_width=None):
         return np.clip(tri + dither, 0, 255).astype(np.uint8)
 
 
+def mixed_band(height):
+    """Rows of the "mixed" image that hold noise: a 128th of the rows, from the middle down."""
+    return height // 2, height // 2 + height // 128
+
+
 def generate(kind, width, height, seed=None, chunk_rows=1024):
-    """Whole image as uint8 [H, W, 3], produced in row chunks to bound temporaries."""
+    """Whole image as uint8 [H, W, 3], produced in row chunks to bound temporaries.
+
+    "mixed": natural content (seed 1) with a narrow band of noise (seed 42) across the middle -- an
+    image whose mean statistics say "photographic" while a few of its tiles are as dense as noise."""
+    if kind == "mixed":
+        out = generate("natural", width, height, 1, chunk_rows)
+        y0, y1 = mixed_band(height)
+        if y1 > y0:
+            out[y0:y1] = noise(width, height, 42, y0, y1)
+        return out
     fn = {"noise": noise, "natural": natural}[kind]
     if seed is None:
         seed = 42 if kind == "noise" else 1

@@ -35,6 +35,8 @@ CASES = {
     # middle of the density range (150 to 300 bits per block)
     "4k_square_444_q75_noise": (4096, 4096, "444", "q75", "noise", 42, 0),
     "4k_square_420_q75_noise": (4096, 4096, "420", "q75", "noise", 42, 0),
+    # smooth content with a narrow band of noise: the mean block is short, a few tiles are dense
+    "4k_square_420_q90_mixed": (4096, 4096, "420", "q90", "mixed", 0, 0),
     # frames of the batch workload: frame k has seed 1000 + k
     "1080p_420_q90_frame0": (1920, 1080, "420", "q90", "natural", 1000, 0),
     "1080p_420_q90_frame1": (1920, 1080, "420", "q90", "natural", 1001, 0),
@@ -51,7 +53,7 @@ def tables_named(name):
 
 def entry(name):
     w, h, scheme, tn, kind, seed, ri = CASES[name]
-    img = synth.generate(kind, w, h, seed=seed)
+    img = synth.generate(kind, w, h, seed=seed if kind != "mixed" else None)
     qt = tables_named(tn)
     t0 = time.time()
     fast = O.encode(img, T.SCHEMES[scheme], qt, restart_interval=ri, variant="avx2")

@@ -45,13 +45,23 @@ def test_file_coefficients_and_histograms_equal_the_oracles(ctx, name):
     scheme, qt = T.SCHEMES[g["scheme"]], _tables(g["tables"])
     dev = torch.device("cuda", 0)
     rgb = torch.empty(h * w * 3, dtype=torch.uint8, device=dev)
-    ctx.synthetic_images(g["kind"], w, 0, h, g["seed"], rgb.data_ptr(), w * 3)
+    if g["kind"] == "mixed":
+        from jpegenc_amd import synth
+        ctx.synthetic_images("natural", w, 0, h, 1, rgb.data_ptr(), w * 3)
+        y0, y1 = synth.mixed_band(h)
+        ctx.synthetic_images("noise", w, y0, y1, 42, rgb.data_ptr() + y0 * w * 3, w * 3)
+    else:
+        ctx.synthetic_images(g["kind"], w, 0, h, g["seed"], rgb.data_ptr(), w * 3)
     prm = B.make_params(w, h, scheme, qt, restart_interval=g["restart_interval"])
     lay = B.compute_layout(prm)
     out = torch.empty(g["length"] + (1 << 20), dtype=torch.uint8, device=dev)
+    ctx.set_profiling(True)
     n = ctx.encode(rgb.data_ptr(), B.RGB8, w * 3, prm, out.data_ptr(), out.numel())
     assert n == g["length"], name
     assert _sha(out[:n]) == g["sha256"], name
+    # the form of the bit writer is chosen from the histogram pass's statistics, not found by running it again
+    assert ctx.profile_sums()[3] == 1, name
+    ctx.set_profiling(False)
     # the same again: nothing of the first encode may leak into the second (workspace reuse)
     out.fill_(0x5A)
     n = ctx.encode(rgb.data_ptr(), B.RGB8, w * 3, prm, out.data_ptr(), out.numel())
