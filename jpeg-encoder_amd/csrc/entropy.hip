@@ -766,7 +766,7 @@ long long group_slot_bytes(const KGeom& g) {
 // each block's bits in a few private LDS words and the second walk is a copy; otherwise the
 // first walk only measures and every block is walked twice.
 template <bool kPrivate>
-__global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int16_t* __restrict__ coef,
+__global__ __launch_bounds__(kEntThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_encode_bits(KGeom g, const int16_t* __restrict__ coef,
                                                              const u32* __restrict__ tables, u64* __restrict__ state,
                                                              u64* __restrict__ ivOff, u64* __restrict__ result,
                                                              u32* __restrict__ words, u64* __restrict__ hostResult,
@@ -775,6 +775,7 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
     // to date as the words are written, so that no counting pass has to read the stream again
     // (1080p: entropy stage 39 -> 34 us; 8192 x 8192 noise 4:4:4: 0.508 -> 0.491 ms).
     __shared__ u32 tab[4 * 256];
+    __shared__ u32 templates[kPrivate ? 1 : kTabWords];   // token templates for the walk without branches (dense_tokens)
     constexpr int kStageWords = kPrivate ? kEmitStageShort : kEmitStageLong;
     __shared__ u32 stage[kStageWords];
     __shared__ u64 span[2];
@@ -811,12 +812,16 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
         const u32 e = myTables[i];
         tab[i] = (e >> 16) == 0 ? kNoCodeLength << 16 : e;
     }
+    if (!kPrivate) build_token_templates(myTables, templates);
     __syncthreads();
 
     long long iv = 0;
     bool firstOfInterval = false, lastOfInterval = false;
     PosSummary mine = {0u, 0u};
     u32 bits = 0;
+    DenseBlock dense;
+    dense.longRuns = 0;
+    bool denseWave = !kPrivate;   // the wave's blocks have their tokens in registers
     const int c = role.c;
     const int pred = dc_predictor_lanes(role, active ? coef_at(w, 0) : 0, fetchedDc, active);
     if (active) {
@@ -832,6 +837,13 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
             walk_block(w, pred, pv);
             bits = pv.finish();
         } else {
+            dense_tokens(w, pred, templates, (u32)t, dense);
+            bits = dense.maxTok >= kTokAbsent ? kNoCodeLength : dense.bits;
+        }
+        if (!kPrivate && __ballot(dense.longRuns != 0) != 0) {
+            // A run of sixteen zeros or more somewhere in the wave's blocks: the general walk for all of them.
+            denseWave = false;
+            load_block(g, coef, b, w);   // (the registers it came in have gone to the tokens)
             LengthVisitor len{tab + 256 * t, tab + 512 + 256 * t, 0u};
             walk_block(w, pred, len);
             bits = len.bits;
@@ -949,15 +961,22 @@ __global__ __launch_bounds__(kEntThreads) void k_encode_bits(KGeom g, const int1
 #pragma unroll
             for (int k = 0; k < kPrivWords; ++k)
                 if ((u32)(32 * k) < bits) out.or32(start + 32 * k, mine32[k]);
-        } else if (staged) {
-            const int t = c == 0 ? 0 : 1;
-            StageVisitor vis{tab + 256 * t, tab + 512 + 256 * t, stage, (u32)(start - (wordBase << 5))};
-            walk_block(w, pred, vis);
+        } else if (staged && !kPrivate && denseWave) {
+            dense_put(dense, stage, (u32)(start - (wordBase << 5)));
         } else {
+            // The general walk.  Behind the pass without branches the block's registers have gone to its
+            // tokens: the block comes from memory once more (rare: a wave with a long zero run, a tile
+            // too long for the stage).
+            if (!kPrivate) load_block(g, coef, b, w);
             const int t = c == 0 ? 0 : 1;
-            EmitVisitor vis{tab + 256 * t, tab + 512 + 256 * t, out, (long long)(start >> 5), 0, (int)(start & 31), true};
-            walk_block(w, pred, vis);
-            vis.finish();
+            if (staged) {
+                StageVisitor vis{tab + 256 * t, tab + 512 + 256 * t, stage, (u32)(start - (wordBase << 5))};
+                walk_block(w, pred, vis);
+            } else {
+                EmitVisitor vis{tab + 256 * t, tab + 512 + 256 * t, out, (long long)(start >> 5), 0, (int)(start & 31), true};
+                walk_block(w, pred, vis);
+                vis.finish();
+            }
         }
         if (padBits != 0 && g.padOnes) out.or32(start + bits, ((1u << padBits) - 1u) << (32 - padBits));
         if (tailEoi) {

@@ -34,8 +34,11 @@ constexpr u32 kGrpBaseBlocks = 32;               // the tile's base address lies
 
 // Symbol tables in LDS, one word per (table, run, category): rows of 16 categories, 23 rows
 // per AC table (a run of 16..22 in front of a group's first coefficient aliases run & 15),
-// then the DC rows, the end-of-block and the zero-run-length entries.
-constexpr int kTabAcWords = 23 * 16;
+// then the DC rows, the end-of-block and the zero-run-length entries.  The rows lie kTabPitch words
+// apart: with 16 the runs r and r + 2 of one category share a bank (32 banks for dword reads), and the
+// lanes of a lookup differ in little else than their runs.
+constexpr int kTabPitch = JPEGENC_TAB_PITCH;
+constexpr int kTabAcWords = 23 * kTabPitch;
 constexpr int kTabDc = 2 * kTabAcWords;
 constexpr int kTabEob = kTabDc + 32;
 constexpr int kTabZrl = kTabEob + 2;
@@ -258,9 +261,116 @@ __device__ __forceinline__ u32 group_symbol_offset(const GroupFront& f, int j, i
     const int v = (int)(short)(f.d[j >> 1] >> (16 * (j & 1)));
     cat = __builtin_amdgcn_frexp_expf((float)v);   // bits of |v|, 0 for 0
     const u32 run = (u32)__builtin_clz(f.X << (16 - j));
-    u32 off = f.tabBase + (run << 6) + ((u32)cat << 2);
+    u32 off = f.tabBase + run * (kTabPitch * 4u) + ((u32)cat << 2);
     if (j == 0 && f.isK0) off = kTabDc * 4u + f.chroma * 64u + ((u32)cat << 2);
     return off;
+}
+
+// Token templates in LDS (kTabWords words) from a table set (four tables of 256 entries,
+// length << 16 | code), by the 256 threads of a workgroup; the caller passes a barrier afterwards.
+__device__ __forceinline__ void build_token_templates(const u32* __restrict__ src, u32* tab) {
+    for (int i = threadIdx.x; i < kTabWords; i += 256) {
+        u32 e, cat = 0;
+        bool zeroCoef = false;
+        if (i < kTabDc) {
+            const int c = i / kTabAcWords, rem = i - c * kTabAcWords;
+            const int row = rem / kTabPitch;
+            cat = (u32)(rem - row * kTabPitch) & 15u;   // (columns behind the sixteenth are never read)
+            zeroCoef = cat == 0;
+            e = src[(2 + c) * 256 + (((row & 15) << 4) | (int)cat)];
+        } else if (i < kTabEob) {
+            cat = (u32)(i - kTabDc) & 15u;
+            e = src[((i - kTabDc) >> 4) * 256 + (int)cat];
+        } else {
+            e = src[(2 + ((i - kTabEob) & 1)) * 256 + (i < kTabZrl ? 0 : 0xF0)];
+        }
+        const u32 len = e >> 16, code = e & 0xffffu;
+        tab[i] = zeroCoef ? 0u : ((len == 0 || len + cat > 27u) ? kTokAbsent : ((code << cat) | ((len + cat) << 27)));
+    }
+}
+
+// ---- one lane per block, dense content ----------------------------------------------------------
+// For blocks in which most coefficients are not zero (noise, q = 100) the block walk with a
+// branch per coefficient (walk_block) spends its time on branches all lanes take anyway, and
+// walking twice -- once for the length, once for the bits -- does everything twice.  Here a
+// lane turns its block's 64 coefficients into 64 tokens (template | amplitude bits, length in
+// bits 31..27, 0 for a zero coefficient) without a branch, keeps them in registers, and the
+// second pass only puts them where they belong.  Runs of sixteen zeros and more in front of a
+// coefficient (ZRL symbols, Encoder.cpp:318-328) are not coded here: `longRuns` tells that the block
+// has one, and the caller takes the general walk for it.
+struct DenseBlock {
+    u32 tok[64];    // [0] the DC token, [i] coefficient i's, 0 for zero coefficients
+    u32 eob;        // the end-of-block token, 0 when coefficient 63 is not zero (Encoder.cpp:343-347)
+    u32 bits;       // length of the block's bit string
+    u32 maxTok;     // >= kTokAbsent: a symbol without a code
+    u32 longRuns;   // != 0: a non-zero coefficient follows sixteen zeros or more
+};
+
+__device__ __forceinline__ void dense_tokens(const u32 (&w)[32], int pred, const u32* tab, u32 chroma, DenseBlock& d) {
+    const char* acRows = (const char*)tab + chroma * (kTabAcWords * 4u);
+    {   // Encoder.cpp:268-284: the DC term's difference, its category, its amplitude bits
+        const int diff = (int)(short)(w[0] & 0xffffu) - pred;
+        const int cat = __builtin_amdgcn_frexp_expf((float)diff);
+        const u32 e = tab[kTabDc + chroma * 16u + (u32)cat];
+        d.tok[0] = e | __builtin_amdgcn_ubfe((u32)(diff + (diff >> 31)), 0u, (u32)cat);
+    }
+    u32 bits = d.tok[0] >> 27, maxTok = d.tok[0], longRuns = 0;
+    int last = 0;   // index of the last non-zero coefficient (the DC term counts, Encoder.cpp:304-306)
+    // Eight coefficients at a time: their look-ups are all on their way before the first token is put
+    // together (one at a time every look-up is waited for alone), and what a batch adds to the sums is
+    // added there and then.  (The tokens are not used before the second pass; left alone the compiler sinks
+    // their assembly and the sums down to there and keeps template, category, run and coefficient of all 63
+    // alive instead: three hundred registers.)
+#pragma unroll
+    for (int i0 = 0; i0 < 64; i0 += 8) {
+        u32 e[8], amp[8], cat[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k;
+            if (i == 0) continue;
+            const int v = (int)(short)(w[i >> 1] >> (16 * (i & 1)));
+            cat[k] = (u32)__builtin_amdgcn_frexp_expf((float)v);   // 0 for 0
+            const u32 run = (u32)(i - 1 - last);
+            last = v != 0 ? i : last;
+            longRuns += (run & 0x30u) * cat[k];
+            e[k] = *(const u32*)(acRows + (run & 15u) * (kTabPitch * 4u) + (cat[k] << 2));   // column 0: empty
+            amp[k] = (u32)(v + (v >> 31));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k;
+            if (i == 0) continue;
+            const u32 t = e[k] | __builtin_amdgcn_ubfe(amp[k], 0u, cat[k]);
+            d.tok[i] = t;
+            bits += t >> 27;
+            maxTok = max(maxTok, t);
+        }
+        asm volatile("" : "+v"(bits), "+v"(maxTok), "+v"(longRuns), "+v"(last));
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + k != 0) asm volatile("" : "+v"(d.tok[i0 + k]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    d.eob = last != 63 ? tab[kTabEob + chroma] : 0u;
+    d.bits = bits + (d.eob >> 27);
+    d.maxTok = max(maxTok, d.eob);
+    d.longRuns = longRuns;
+}
+
+// ORs the block's tokens into the (zeroed) stage in LDS, the first at bit position pos (counted
+// from bit 31 of stage word 0).
+__device__ __forceinline__ void dense_put(const DenseBlock& d, u32* stage, u32 pos) {
+#pragma unroll
+    for (int i = 0; i < 65; ++i) {
+        const u32 t = i < 64 ? d.tok[i] : d.eob;
+        const u32 len = t >> 27, sh = pos & 31u;
+        const u64 v = (u64)(t & 0x07ffffffu) << ((64u - sh - len) & 63u);   // (nothing to shift when len == 0)
+        u32* at = stage + (pos >> 5);
+        atomicOr(at, (u32)(v >> 32));
+        atomicOr(at + 1, (u32)v);
+        pos += len;
+        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // ---- histograms ------------------------------------------------------------------------------
@@ -605,26 +715,7 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
     __syncthreads();
     const u32 tile = (u32)__builtin_amdgcn_readfirstlane((u32)ticket) + (u32)wave;
     const u32 image = tile / tilesPerImage;
-    {   // token templates from the image's tables (entries: length << 16 | code)
-        const u32* src = tables + (long long)image * g.tableStride;
-        for (int i = threadIdx.x; i < kTabWords; i += 256) {
-            u32 e, cat = 0;
-            bool zeroCoef = false;
-            if (i < kTabDc) {
-                const int c = i / kTabAcWords, rem = i - c * kTabAcWords;
-                cat = (u32)rem & 15u;
-                zeroCoef = cat == 0;
-                e = src[(2 + c) * 256 + ((((rem >> 4) & 15) << 4) | (int)cat)];
-            } else if (i < kTabEob) {
-                cat = (u32)(i - kTabDc) & 15u;
-                e = src[((i - kTabDc) >> 4) * 256 + (int)cat];
-            } else {
-                e = src[(2 + ((i - kTabEob) & 1)) * 256 + (i < kTabZrl ? 0 : 0xF0)];
-            }
-            const u32 len = e >> 16, code = e & 0xffffu;
-            tab[i] = zeroCoef ? 0u : ((len == 0 || len + cat > 27u) ? kTokAbsent : ((code << cat) | ((len + cat) << 27)));
-        }
-    }
+    build_token_templates(tables + (long long)image * g.tableStride, tab);
     __syncthreads();
     // No workgroup barrier from here on: the waves go their own ways (a wave's look-back may
     // wait for a tile of another wave of the same workgroup).
