@@ -189,7 +189,7 @@ void fill_kgeom(jpeg_hip_ctx* ctx) {
     k.mcusPerImage = g.nMcu;
     k.blocksPerImage = g.totalBlocks;
     k.imageStrideBytes = 0;
-    k.tableStride = 1024;
+    k.tableStride = kTabImageWords;
     k.nGains = 0;
     k.groupMask = (const unsigned char*)ctx->gmask.p;
     // Large images keep groups 0..3 of all blocks in the first half of the coefficient buffer
@@ -287,9 +287,7 @@ hipError_t wait_event(hipEvent_t ev) {
 // Packs the tables for the kernels next to the headerLen bytes of file header already placed
 // in the pinned block.
 int install_tables(jpeg_hip_ctx* ctx, int headerLen = 0) {
-    for (int t = 0; t < 4; ++t)
-        for (int s = 0; s < 256; ++s)
-            ctx->pin->tables[t * 256 + s] = ((uint32_t)ctx->lengths[t][s] << 16) | ctx->codes[t][s];
+    fill_table_image(ctx->lengths, ctx->codes, ctx->pin->tables);
     // They stay in the pinned block until the entropy stage runs: its first kernel fetches
     // them from there (run_entropy).
     ctx->tablesPending = true;
@@ -1219,8 +1217,8 @@ void batch_tables_worker(const jpeg_hip_ctx* ctx, int k0, int k1, const uint64_t
                 return;
             }
             huffman_from_histogram(h + t * 256, lengths[t], codes[t]);
-            for (int s = 0; s < 256; ++s) tables[(size_t)k * 1024 + t * 256 + s] = ((uint32_t)lengths[t][s] << 16) | codes[t][s];
         }
+        fill_table_image(lengths, codes, tables + (size_t)k * kTabImageWords);
         const int n = write_headers(ctx->prm, ctx->geo, lengths, codes, hdr + (size_t)k * kBatchHeaderPitch, kBatchHeaderPitch);
         if (n < 0) {
             *status = n;
@@ -1311,7 +1309,7 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
             h.k.totalBlocks = g.totalBlocks * h.cnt;
             h.k.groupMask = (const unsigned char*)ctx->gmask.p + (int64_t)h.a * g.totalBlocks;
             h.coef = (const int16_t*)ctx->coef.p + (int64_t)h.a * g.totalBlocks * (k.coefPitch / 2);
-            h.tables = (const uint32_t*)ctx->tables.p + (h.k.tableStride ? (size_t)h.a * 1024 : 0);
+            h.tables = (const uint32_t*)ctx->tables.p + (h.k.tableStride ? (size_t)h.a * kTabImageWords : 0);
             h.ws = ctx->ws;
             h.ws.tileSlots = slots ? slots + (i == 1 ? group_slot_bytes(half[0].k) / 4 : 0) : nullptr;
             if (i == 1) {   // behind the first half's slices
@@ -1352,9 +1350,7 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
         uint8_t lengths[4][256];
         uint16_t codes[4][256];
         standard_huffman(lengths, codes);
-        uint32_t* tables = (uint32_t*)ctx->hostTables.p;
-        for (int t = 0; t < 4; ++t)
-            for (int s = 0; s < 256; ++s) tables[t * 256 + s] = ((uint32_t)lengths[t][s] << 16) | codes[t][s];
+        fill_table_image(lengths, codes, (uint32_t*)ctx->hostTables.p);
         uint8_t* hdr = (uint8_t*)ctx->hostHdr.p;
         const int hn = write_headers(ctx->prm, ctx->geo, lengths, codes, hdr, kBatchHeaderPitch);
         if (hn < 0) return fail(ctx, hn, "header assembly failed");
@@ -1448,8 +1444,8 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
         taskBase += partTasks;
         // The part's tables and headers travel while the device is still busy with later parts.
         const size_t cnt = (size_t)(a1 - a0);
-        HIP_TRY(ctx, hipMemcpyAsync((uint32_t*)ctx->tables.p + (size_t)a0 * 1024, (const uint32_t*)ctx->hostTables.p + (size_t)a0 * 1024,
-                                    cnt * 1024 * 4, hipMemcpyHostToDevice, ctx->tableStream));
+        HIP_TRY(ctx, hipMemcpyAsync((uint32_t*)ctx->tables.p + (size_t)a0 * kTabImageWords, (const uint32_t*)ctx->hostTables.p + (size_t)a0 * kTabImageWords,
+                                    cnt * kTabImageWords * 4, hipMemcpyHostToDevice, ctx->tableStream));
         HIP_TRY(ctx, hipMemcpyAsync((uint8_t*)ctx->batchHdr.p + (size_t)a0 * kBatchHeaderPitch,
                                     (const uint8_t*)ctx->hostHdr.p + (size_t)a0 * kBatchHeaderPitch, cnt * kBatchHeaderPitch,
                                     hipMemcpyHostToDevice, ctx->tableStream));
@@ -1478,7 +1474,7 @@ int encode_batch_pass(jpeg_hip_ctx* ctx, const uint8_t* d_rgb, int64_t imageStri
     }
 
     if (standard) {
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->hostTables.p, 1024 * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->tables.p, ctx->hostTables.p, kTabImageWords * 4, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->batchHdr.p, ctx->hostHdr.p, (size_t)n * kBatchHeaderPitch, hipMemcpyHostToDevice,
                                     ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->batchHdrLen.p, ctx->hostHdrLen.p, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1569,7 +1565,7 @@ int prepare_batch(jpeg_hip_ctx* ctx, const void* rgb, int sample_format, int64_t
     HIP_TRY(ctx, ctx->batchHdrLen.ensure((size_t)pass * 4));
     HIP_TRY(ctx, ctx->batchFfStart.ensure((size_t)(pass + 2) * 8));
     HIP_TRY(ctx, ctx->hostHist.ensure((size_t)pass * 1024 * 8));
-    HIP_TRY(ctx, ctx->hostTables.ensure((size_t)pass * 1024 * 4));
+    HIP_TRY(ctx, ctx->hostTables.ensure((size_t)pass * kTabImageWords * 4));
     HIP_TRY(ctx, ctx->hostHdr.ensure((size_t)pass * kBatchHeaderPitch));
     HIP_TRY(ctx, ctx->hostHdrLen.ensure((size_t)pass * 4));
     HIP_TRY(ctx, ctx->hostOffsets.ensure((size_t)(2 * (pass + 2) + 8) * 8));

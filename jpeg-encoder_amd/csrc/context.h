@@ -80,7 +80,7 @@ constexpr int kHeaderCapacity = 2048;
 struct Pinned {
     float qtab[3 * 192];   // divisors, then the high and low parts of their reciprocals
     uint64_t hist[4 * 256];
-    uint32_t tables[4 * 256];           // tables and header travel to the device in one copy
+    uint32_t tables[kTabImageWords];    // table image (kernels.h) and header travel to the device in one copy
     uint8_t header[kHeaderCapacity];
     uint64_t result[4];
     uint64_t exchangeFlag;              // failure flags of a sharded encode, to and from the device
@@ -184,7 +184,7 @@ inline WorkspaceSizes workspace_sizes(const Geometry& g, int images, int64_t uns
     w.gmask = (size_t)nb + 64;   // one byte per block, read in dwords
     w.qtab = sizeof(Pinned::qtab);
     w.hist = 1024 * sizeof(uint64_t) * (size_t)images;
-    w.tables = 1024 * sizeof(uint32_t) * (size_t)images + kHeaderCapacity;
+    w.tables = kTabImageWords * sizeof(uint32_t) * (size_t)images + kHeaderCapacity;
     w.ivOff = (size_t)(intervals + 1) * 8;
     w.ffCount = (size_t)w.maxChunks * 4;
     w.groupSum = (size_t)(w.maxChunks / 64 + 2) * 8;

@@ -787,6 +787,18 @@ __global__ __launch_bounds__(kEntThreads) __attribute__((amdgpu_waves_per_eu(4, 
     const long long tiles = tilesPerImage * g.batch;
     u64* counter = state + tiles;
     if (threadIdx.x == 0) tileNo = (long long)atomicAdd((unsigned long long*)counter, 1ull);
+    // One picture: the tables do not depend on the tile, and come in while the ticket is on its way
+    // (a round trip to memory that every tile of the launch is queueing for).
+    // A symbol the tables have no code for (length 0) gets a length no block can reach, so
+    // that a block which uses one shows in its bit count.
+    auto stage_tables = [&](const u32* image) {
+        for (int i = threadIdx.x; i < 1024; i += kEntThreads) {
+            const u32 e = image[i];
+            tab[i] = (e >> 16) == 0 ? kNoCodeLength << 16 : e;
+        }
+        if (!kPrivate) load_token_templates(image, templates);
+    };
+    if (g.batch == 1) stage_tables(tables);
     __syncthreads();
     // Tile and block numbers fit 32 bits (see BlockRole); the tile number is the same for
     // the whole workgroup.
@@ -805,15 +817,10 @@ __global__ __launch_bounds__(kEntThreads) __attribute__((amdgpu_waves_per_eu(4, 
         load_block(g, coef, b, w);
         fetchedDc = load_dc(g, coef, dc_predictor_source(role, b));
     }
-    const u32* myTables = tables + image * g.tableStride;
-    // A symbol the tables have no code for (length 0) gets a length no block can reach, so
-    // that a block which uses one shows in its bit count.
-    for (int i = threadIdx.x; i < 1024; i += kEntThreads) {
-        const u32 e = myTables[i];
-        tab[i] = (e >> 16) == 0 ? kNoCodeLength << 16 : e;
+    if (g.batch > 1) {
+        stage_tables(tables + image * g.tableStride);
+        __syncthreads();
     }
-    if (!kPrivate) build_token_templates(myTables, templates);
-    __syncthreads();
 
     long long iv = 0;
     bool firstOfInterval = false, lastOfInterval = false;
@@ -1366,9 +1373,9 @@ __global__ __launch_bounds__(256) void k_prepare_entropy(uint4* __restrict__ str
     if (pending != nullptr) {
         // Tables and header still sit in pinned host memory: bring them over (the device
         // copy serves later launches) and take the header for the output from there.
-        const int words = 1024 + (hdrLen + 3) / 4;
+        const int words = kTabImageWords + (hdrLen + 3) / 4;
         for (long long i = tid; i < words; i += step) tables[i] = pending[i];
-        hdr = (const uint8_t*)(pending + 1024);
+        hdr = (const uint8_t*)(pending + kTabImageWords);
     }
     for (long long i = tid; i < stream16; i += step) stream[i] = make_uint4(0, 0, 0, 0);
     for (long long i = tid; i < tileWords; i += step) tileState[i] = 0;

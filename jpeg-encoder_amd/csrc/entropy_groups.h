@@ -32,22 +32,7 @@ constexpr int kGrpMinIntervalBlocks = 16;
 constexpr long long kGrpMinBlocks = 150000;       // images (or batches) below this many blocks keep the one-lane-per-block writer (entropy stage at 98 k blocks: 39 against 42 us; at 197 k: 49 against 45)
 constexpr u32 kGrpBaseBlocks = 32;               // the tile's base address lies this many blocks in front of its first block
 
-// Symbol tables in LDS, one word per (table, run, category): rows of 16 categories, 23 rows
-// per AC table (a run of 16..22 in front of a group's first coefficient aliases run & 15),
-// then the DC rows, the end-of-block and the zero-run-length entries.  The rows lie kTabPitch words
-// apart: with 16 the runs r and r + 2 of one category share a bank (32 banks for dword reads), and the
-// lanes of a lookup differ in little else than their runs.
-constexpr int kTabPitch = JPEGENC_TAB_PITCH;
-constexpr int kTabAcWords = 23 * kTabPitch;
-constexpr int kTabDc = 2 * kTabAcWords;
-constexpr int kTabEob = kTabDc + 32;
-constexpr int kTabZrl = kTabEob + 2;
-constexpr int kTabWords = kTabZrl + 2;
-// A token: the symbol's code shifted left by the category, so that the amplitude bits can be
-// ORed in, in bits 26..0 and the total number of bits (code + amplitude, at most 27) in bits
-// 31..27.  Symbols of category 0 inside the AC rows stand for zero coefficients: empty.
-constexpr u32 kTokAbsent = 0xF8000000u;          // the table has no code for a symbol (31 is no length)
-
+// Token templates in LDS: see kTabPitch in kernels.h.
 // An item of a tile's list: (block inside the tile << 4) | group; group 8 stands for the end
 // of a restart interval behind the block's last group.
 constexpr u32 kItemNone = 0xffffu;
@@ -266,27 +251,10 @@ __device__ __forceinline__ u32 group_symbol_offset(const GroupFront& f, int j, i
     return off;
 }
 
-// Token templates in LDS (kTabWords words) from a table set (four tables of 256 entries,
-// length << 16 | code), by the 256 threads of a workgroup; the caller passes a barrier afterwards.
-__device__ __forceinline__ void build_token_templates(const u32* __restrict__ src, u32* tab) {
-    for (int i = threadIdx.x; i < kTabWords; i += 256) {
-        u32 e, cat = 0;
-        bool zeroCoef = false;
-        if (i < kTabDc) {
-            const int c = i / kTabAcWords, rem = i - c * kTabAcWords;
-            const int row = rem / kTabPitch;
-            cat = (u32)(rem - row * kTabPitch) & 15u;   // (columns behind the sixteenth are never read)
-            zeroCoef = cat == 0;
-            e = src[(2 + c) * 256 + (((row & 15) << 4) | (int)cat)];
-        } else if (i < kTabEob) {
-            cat = (u32)(i - kTabDc) & 15u;
-            e = src[((i - kTabDc) >> 4) * 256 + (int)cat];
-        } else {
-            e = src[(2 + ((i - kTabEob) & 1)) * 256 + (i < kTabZrl ? 0 : 0xF0)];
-        }
-        const u32 len = e >> 16, code = e & 0xffffu;
-        tab[i] = zeroCoef ? 0u : ((len == 0 || len + cat > 27u) ? kTokAbsent : ((code << cat) | ((len + cat) << 27)));
-    }
+// The token templates of a table image (kernels.h) into LDS, by the 256 threads of a workgroup; the
+// caller passes a barrier afterwards.
+__device__ __forceinline__ void load_token_templates(const u32* __restrict__ image, u32* tab) {
+    for (int i = threadIdx.x; i < kTabWords; i += 256) tab[i] = image[kTabTemplates + i];
 }
 
 // ---- one lane per block, dense content ----------------------------------------------------------
@@ -712,11 +680,14 @@ __global__ __launch_bounds__(256) void k_encode_groups(KGeom g, const int16_t* _
     // streaming loads and leaves it there).
     if (threadIdx.x == 0) ticket = kDeferred ? 4ull * (gridDim.x - 1u - blockIdx.x) : atomicAdd((unsigned long long*)(state + tiles), 4ull);
     for (int i = threadIdx.x; i < 4 * kGrpStageWords; i += 256) (&stage[0][0])[i] = 0;
+    if (g.batch == 1) load_token_templates(tables, tab);   // (one picture: they come in while the ticket is on its way)
     __syncthreads();
     const u32 tile = (u32)__builtin_amdgcn_readfirstlane((u32)ticket) + (u32)wave;
     const u32 image = tile / tilesPerImage;
-    build_token_templates(tables + (long long)image * g.tableStride, tab);
-    __syncthreads();
+    if (g.batch > 1) {
+        load_token_templates(tables + (long long)image * g.tableStride, tab);
+        __syncthreads();
+    }
     // No workgroup barrier from here on: the waves go their own ways (a wave's look-back may
     // wait for a tile of another wave of the same workgroup).
 

@@ -35,7 +35,7 @@ struct KGeom {
     long long mcusPerImage;
     long long blocksPerImage;
     long long imageStrideBytes;
-    int tableStride;             // entries between the Huffman table sets of consecutive images (0: one shared set)
+    int tableStride;             // words between the table images of consecutive pictures (kTabImageWords, or 0: one shared set)
     // One byte per block of the band (or batch), written by the transform: bit k is set when the
     // block's k-th group of eight zig-zag ordered coefficients is not all zero.
     const unsigned char* groupMask;
@@ -86,7 +86,7 @@ struct EntropyWorkspace {
     uint32_t* tileSlots;
     const uint8_t* header;           // file header staged in device memory, copied to the front of the output
     int headerLen;                   // (0: none); prefixLen of launch_entropy covers it
-    // Tables (uint32[4][256]) and, right behind them, headerLen header bytes in pinned host
+    // A table image (kTabImageWords words) and, right behind it, headerLen header bytes in pinned host
     // memory that have not been sent to the device yet, or null: the first kernel of the
     // stage fetches them into d_tables / header itself, which is cheaper than a copy call.
     const uint32_t* pendingTables;
@@ -95,6 +95,56 @@ struct EntropyWorkspace {
     // no copy after the stage (cleared by the host before the launch).
     unsigned long long* hostResult;
 };
+
+// ---- Huffman tables as the kernels read them ---------------------------------------------------
+// A table set travels from the host as one image of kTabImageWords words per picture: the four
+// tables as they are (256 entries each, length << 16 | code; order DC-Y, DC-C, AC-Y, AC-C) and,
+// behind them, the token templates the bit writers look up, built once on the host instead of
+// by every workgroup: one word per (table, run, category) -- the symbol's code shifted left by the
+// category, so that the amplitude bits can be ORed in, in bits 26..0 and the total number of bits
+// (code + amplitude, at most 27) in bits 31..27.  Rows of 16 categories lie kTabPitch words apart
+// (with 16 the runs r and r + 2 of one category share an LDS bank: 32 banks for dword reads, and
+// the lanes of a look-up differ in little else than their runs), 23 rows per AC table (a run of
+// 16..22 in front of a group's first coefficient aliases run & 15), then the DC rows, the
+// end-of-block and the zero-run-length entries.  Category 0 inside the AC rows stands for a zero
+// coefficient: an empty token.
+constexpr int kTabPitch = 17;
+constexpr int kTabAcWords = 23 * kTabPitch;
+constexpr int kTabDc = 2 * kTabAcWords;
+constexpr int kTabEob = kTabDc + 32;
+constexpr int kTabZrl = kTabEob + 2;
+constexpr int kTabWords = kTabZrl + 2;
+constexpr int kTabTemplates = 1024;                               // where the templates start inside an image
+constexpr int kTabImageWords = (kTabTemplates + kTabWords + 3) / 4 * 4;   // (whole 16-byte pieces)
+constexpr uint32_t kTokAbsent = 0xF8000000u;                      // the table has no code for a symbol (31 is no length)
+
+// Template word i (0 <= i < kTabWords) of a table set.
+inline uint32_t token_template(const uint32_t* src, int i) {
+    uint32_t e, cat = 0;
+    bool zeroCoef = false;
+    if (i < kTabDc) {
+        const int c = i / kTabAcWords, rem = i - c * kTabAcWords;
+        const int row = rem / kTabPitch;
+        cat = (uint32_t)(rem - row * kTabPitch) & 15u;   // (columns behind the sixteenth are never read)
+        zeroCoef = cat == 0;
+        e = src[(2 + c) * 256 + (((row & 15) << 4) | (int)cat)];
+    } else if (i < kTabEob) {
+        cat = (uint32_t)(i - kTabDc) & 15u;
+        e = src[((i - kTabDc) >> 4) * 256 + (int)cat];
+    } else {
+        e = src[(2 + ((i - kTabEob) & 1)) * 256 + (i < kTabZrl ? 0 : 0xF0)];
+    }
+    const uint32_t len = e >> 16, code = e & 0xffffu;
+    return zeroCoef ? 0u : ((len == 0 || len + cat > 27u) ? kTokAbsent : ((code << cat) | ((len + cat) << 27)));
+}
+
+// Fills a table image from lengths and codes (uint8/uint16 [4][256]).
+inline void fill_table_image(const uint8_t lengths[4][256], const uint16_t codes[4][256], uint32_t* image) {
+    for (int t = 0; t < 4; ++t)
+        for (int s = 0; s < 256; ++s) image[t * 256 + s] = ((uint32_t)lengths[t][s] << 16) | codes[t][s];
+    for (int i = 0; i < kTabWords; ++i) image[kTabTemplates + i] = token_template(image, i);
+    for (int i = kTabTemplates + kTabWords; i < kTabImageWords; ++i) image[i] = 0;
+}
 
 constexpr int kStuffChunk = 4096;   // unstuffed bytes handled by one workgroup pass
 
