@@ -477,7 +477,6 @@ __device__ __forceinline__ bool interval_has_eoi(const KGeom& g, long long k) {
 // range's first and last word are merged into the zeroed buffer with atomicOr.  Ranges too
 // long for the LDS stage are written straight to memory.
 constexpr int kEmitStageShort = 2048;   // stage words of a tile of short blocks (8 bytes per block on average)
-constexpr int kEmitStageLong = 6144;    // ... of long blocks (up to 96 bytes per block on average)
 
 // Where a lane's bits go: the LDS stage (native order) or the global stream (swapped).
 struct BitTarget {
@@ -485,13 +484,24 @@ struct BitTarget {
     long long bias;   // index of the stream word that words[0] stands for
     bool swap;
     u32* ff;          // per-chunk 0xFF counts to keep up to date when the target is the stream itself, or null
+    // Stream words that do not go to memory but to two words in LDS (a tile's first and last word,
+    // which k_merge_edges writes): edge is null when there are none.
+    u32* edge;
+    long long edgeLo, edgeHi;
+    __device__ __forceinline__ bool diverted(long long index, u32 v) const {
+        if (edge == nullptr || (index != edgeLo && index != edgeHi)) return false;
+        atomicOr(&edge[index == edgeLo ? 0 : 1], __builtin_bswap32(v));
+        return true;
+    }
     __device__ __forceinline__ void or_word(long long index, u32 v) const {
         if (v == 0) return;
+        if (diverted(index, v)) return;
         if (swap && ff != nullptr) or_counted(words, (u64)index, __builtin_bswap32(v), ff);
         else atomicOr(&words[index - bias], swap ? __builtin_bswap32(v) : v);
     }
     // A whole word of the stream that belongs to the caller alone.
     __device__ __forceinline__ void store_word(long long index, u32 v) const {
+        if (diverted(index, v)) return;
         words[index - bias] = swap ? __builtin_bswap32(v) : v;
         if (swap && ff != nullptr) {
             const u32 n = (u32)__popc(ff_bits(v));
@@ -714,6 +724,7 @@ __device__ __forceinline__ bool look_back(const u64* state, long long tile, u64 
 }
 
 #include "entropy_groups.h"
+#include "entropy_dense.h"
 
 // It pays from about a quarter of a million blocks on (tiles of 256 blocks, natural content, against
 // k_histogram: 49 k blocks 19 against 13 us, 98 k 20 against 17, 197 k 21 against 20, 393 k 23 against 29,
@@ -762,10 +773,8 @@ long long group_slot_bytes(const KGeom& g) {
     return group_tiles_per_image(g.blocksPerImage, kGrpTileBlocks) * g.batch * (long long)kGrpSlotWords * 4;
 }
 
-// kPrivate: blocks are short on average (photographic content), so the first walk keeps
-// each block's bits in a few private LDS words and the second walk is a copy; otherwise the
-// first walk only measures and every block is walked twice.
-template <bool kPrivate>
+// Blocks that are short on average (photographic content; k_encode_dense has the long ones): the
+// first walk keeps each block's bits in a few private LDS words and the second is a copy.
 __global__ __launch_bounds__(kEntThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_encode_bits(KGeom g, const int16_t* __restrict__ coef,
                                                              const u32* __restrict__ tables, u64* __restrict__ state,
                                                              u64* __restrict__ ivOff, u64* __restrict__ result,
@@ -775,12 +784,11 @@ __global__ __launch_bounds__(kEntThreads) __attribute__((amdgpu_waves_per_eu(4, 
     // to date as the words are written, so that no counting pass has to read the stream again
     // (1080p: entropy stage 39 -> 34 us; 8192 x 8192 noise 4:4:4: 0.508 -> 0.491 ms).
     __shared__ u32 tab[4 * 256];
-    __shared__ u32 templates[kPrivate ? 1 : kTabWords];   // token templates for the walk without branches (dense_tokens)
-    constexpr int kStageWords = kPrivate ? kEmitStageShort : kEmitStageLong;
+    constexpr int kStageWords = kEmitStageShort;
     __shared__ u32 stage[kStageWords];
     __shared__ u64 span[2];
     __shared__ PosSummary waveSum[kEntThreads / 64];
-    __shared__ u32 priv[kPrivate ? kEntThreads * kPrivPitch : 1];
+    __shared__ u32 priv[kEntThreads * kPrivPitch];
     __shared__ u64 tileStart;
     __shared__ long long tileNo;
     const long long tilesPerImage = (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
@@ -796,7 +804,6 @@ __global__ __launch_bounds__(kEntThreads) __attribute__((amdgpu_waves_per_eu(4, 
             const u32 e = image[i];
             tab[i] = (e >> 16) == 0 ? kNoCodeLength << 16 : e;
         }
-        if (!kPrivate) load_token_templates(image, templates);
     };
     if (g.batch == 1) stage_tables(tables);
     __syncthreads();
@@ -826,9 +833,6 @@ __global__ __launch_bounds__(kEntThreads) __attribute__((amdgpu_waves_per_eu(4, 
     bool firstOfInterval = false, lastOfInterval = false;
     PosSummary mine = {0u, 0u};
     u32 bits = 0;
-    DenseBlock dense;
-    dense.longRuns = 0;
-    bool denseWave = !kPrivate;   // the wave's blocks have their tokens in registers
     const int c = role.c;
     const int pred = dc_predictor_lanes(role, active ? coef_at(w, 0) : 0, fetchedDc, active);
     if (active) {
@@ -839,22 +843,9 @@ __global__ __launch_bounds__(kEntThreads) __attribute__((amdgpu_waves_per_eu(4, 
         firstOfInterval = b == ivFirstBlock;
         lastOfInterval = b == ivEnd - 1;
         const int t = c == 0 ? 0 : 1;
-        if (kPrivate) {
-            PrivateVisitor pv{tab + 256 * t, tab + 512 + 256 * t, priv + threadIdx.x * kPrivPitch, 0, 0, 0};
-            walk_block(w, pred, pv);
-            bits = pv.finish();
-        } else {
-            dense_tokens(w, pred, templates, (u32)t, dense);
-            bits = dense.maxTok >= kTokAbsent ? kNoCodeLength : dense.bits;
-        }
-        if (!kPrivate && __ballot(dense.longRuns != 0) != 0) {
-            // A run of sixteen zeros or more somewhere in the wave's blocks: the general walk for all of them.
-            denseWave = false;
-            load_block(g, coef, b, w);   // (the registers it came in have gone to the tokens)
-            LengthVisitor len{tab + 256 * t, tab + 512 + 256 * t, 0u};
-            walk_block(w, pred, len);
-            bits = len.bits;
-        }
+        PrivateVisitor pv{tab + 256 * t, tab + 512 + 256 * t, priv + threadIdx.x * kPrivPitch, 0, 0, 0};
+        walk_block(w, pred, pv);
+        bits = pv.finish();
         if (bits >= kNoCodeLength) {   // report it and write nothing for the block
             atomicOr((unsigned long long*)&result[1], 16ull);
             bits = 0;
@@ -955,7 +946,7 @@ __global__ __launch_bounds__(kEntThreads) __attribute__((amdgpu_waves_per_eu(4, 
         __syncthreads();
     }
     if (active) {
-        const BitTarget out{staged ? stage : words, staged ? (long long)wordBase : 0, !staged, ffCount};
+        const BitTarget out{staged ? stage : words, staged ? (long long)wordBase : 0, !staged, ffCount, nullptr, 0, 0};
         const u64 start = pos + (leadMarker ? 16 : 0);   // first bit of the block itself
         if (leadMarker) {
             out.or32(pos, leadMarker << 16);
@@ -963,19 +954,13 @@ __global__ __launch_bounds__(kEntThreads) __attribute__((amdgpu_waves_per_eu(4, 
         }
         if (bits == 0) {
             // a block with a symbol that has no code: flagged above
-        } else if (kPrivate && bits <= (u32)(kPrivWords * 32)) {
+        } else if (bits <= (u32)(kPrivWords * 32)) {
             const u32* mine32 = priv + threadIdx.x * kPrivPitch;
 #pragma unroll
             for (int k = 0; k < kPrivWords; ++k)
                 if ((u32)(32 * k) < bits) out.or32(start + 32 * k, mine32[k]);
-        } else if (staged && !kPrivate && denseWave) {
-            dense_put(dense, stage, (u32)(start - (wordBase << 5)));
         } else {
-            // The general walk.  Behind the pass without branches the block's registers have gone to its
-            // tokens: the block comes from memory once more (rare: a wave with a long zero run, a tile
-            // too long for the stage).
-            if (!kPrivate) load_block(g, coef, b, w);
-            const int t = c == 0 ? 0 : 1;
+            const int t = c == 0 ? 0 : 1;   // a block too long for its private words: walked once more
             if (staged) {
                 StageVisitor vis{tab + 256 * t, tab + 512 + 256 * t, stage, (u32)(start - (wordBase << 5))};
                 walk_block(w, pred, vis);
@@ -1403,20 +1388,25 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     // (Not when the tiles' bits are placed by k_place_tiles and k_merge_edges: those write every
     // word of the stream exactly once, with plain stores.)
     const bool deferred = groups && ws.tileSlots != nullptr && ws.groupTile == kGrpTileBlocks;
-    const long long clear16 = deferred ? 0 : zero / 16;
     // The kernels that write the stream keep the per-chunk counts of its 0xFF bytes.
     const bool shortBlocks = ws.avgBlockBits <= 128;   // long blocks (noise, q=100) do not fit the private words; unknown lengths count as short
-    long long prepGrid = (clear16 > tileCount / 2 ? clear16 : tileCount / 2) / (256 * 4);
-    prepGrid = prepGrid < 1 ? 1 : (prepGrid > 2048 ? 2048 : prepGrid);
+    const bool dense = !groups && !shortBlocks;   // (k_encode_dense writes every word once as well)
+    const long long clear16 = deferred || dense ? 0 : zero / 16;
     // Chunks the stream can have at most: from the bound that was cleared.
     long long chunkBound = zero / kStuffChunk + 1;
     if (chunkBound > ws.maxChunks) chunkBound = ws.maxChunks;
+    // (every thread four 16-byte stores, or a handful of the small words: the per-chunk counts, the tile states)
+    long long prepWork = clear16 > tileCount / 2 ? clear16 : tileCount / 2;
+    if (chunkBound / 4 > prepWork) prepWork = chunkBound / 4;
+    long long prepGrid = prepWork / (256 * 4);
+    prepGrid = prepGrid < 1 ? 1 : (prepGrid > 2048 ? 2048 : prepGrid);
     // Tile states: the chaining tiles start from zeros (and a zero ticket counter behind them); deferred
     // tiles write theirs before anybody reads them, and only the word k_tile_positions counts its waves
     // off with has to be zero.
     const long long deferredRuns = (tileCount + 63) / 64;
     u64* clearStates = deferred ? ws.tileState + tileCount + deferredRuns : ws.tileState;
-    const long long clearStateWords = deferred ? 1 : tileCount + 1;
+    // (k_encode_dense: the tiles' states, its ticket counter and the count of its list)
+    const long long clearStateWords = deferred ? 1 : tileCount + 2;
     hipLaunchKernelGGL(k_prepare_entropy, dim3((unsigned)prepGrid), dim3(256), 0, s, (uint4*)ws.unstuffed, clear16,
                        clearStates, clearStateWords, ws.result, ws.header, bo ? 0 : ws.headerLen, d_out,
                        bo ? nullptr : ws.pendingTables, const_cast<u32*>(d_tables), ws.ffCount, chunkBound);
@@ -1432,19 +1422,27 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
                            runStart + runs);   // (a word the clearing kernel has zeroed)
         hipLaunchKernelGGL(k_place_tiles, dim3((unsigned)((tileCount + 3) / 4)), dim3(256), 0, s, g, ws.tileState, runStart,
                            ws.tileSlots, ws.ivOff, ws.result, (u32*)ws.unstuffed, (u32)tileCount, zero, ws.ffCount);
-        hipLaunchKernelGGL(k_merge_edges, dim3((unsigned)((4 * tileCount + 255) / 256)), dim3(256), 0, s, g, ws.tileSlots,
-                           (u32*)ws.unstuffed, (u32)tileCount, ws.ffCount);
+        hipLaunchKernelGGL(k_merge_edges, dim3((unsigned)((4 * tileCount + 255) / 256)), dim3(256), 0, s, g,
+                           ws.tileSlots + kGrpSlotEdges, (u32)kGrpSlotWords, 2u, (u32*)ws.unstuffed, (u32)tileCount, ws.ffCount);
     } else if (groups)
         hipLaunchKernelGGL(k_encode_groups<false>, dim3((unsigned)(tileCount / 4)), dim3(256), 0, s, g, d_coef, d_tables, ws.tileState,
                            ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero, nullptr, ws.ffCount);
     else if (shortBlocks)
-        hipLaunchKernelGGL(k_encode_bits<true>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
+        hipLaunchKernelGGL(k_encode_bits, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
                            ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult, zero,
                            ws.ffCount);
-    else
-        hipLaunchKernelGGL(k_encode_bits<false>, dim3((unsigned)tileCount), dim3(kEntThreads), 0, s, g, d_coef, d_tables,
-                           ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult, zero,
-                           ws.ffCount);
+    else {
+        // As many workgroups as the device holds at once (four per CU, by registers and LDS); each takes tile
+        // after tile.  (Diagnostic switch JPEGENC_DENSE_GRID: another number.)
+        static const long long denseGrid = getenv("JPEGENC_DENSE_GRID") ? atoll(getenv("JPEGENC_DENSE_GRID")) : 1024;
+        const unsigned grid = (unsigned)(tileCount < denseGrid ? tileCount : denseGrid);
+        hipLaunchKernelGGL(k_encode_dense, dim3(grid), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.tileState, ws.ivOff,
+                           ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult, zero, ws.ffCount);
+        hipLaunchKernelGGL(k_encode_dense_rest, dim3(grid < 256u ? grid : 256u), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.tileState, ws.ivOff,
+                           ws.result, (u32*)ws.unstuffed, zero, ws.ffCount);
+        hipLaunchKernelGGL(k_merge_edges, dim3((unsigned)((2 * tileCount + 255) / 256)), dim3(256), 0, s, g,
+                           (const u32*)(ws.tileState + tileCount + 2), 4u, 1u, (u32*)ws.unstuffed, (u32)tileCount, ws.ffCount);
+    }
     // As many workgroups as the device holds at once (five per CU): a workgroup's run of chunks is
     // one chain (a chunk's bytes are asked for while the chunk in front is worked on), a second
     // round of workgroups would start that chain all over.  (Diagnostic switch JPEGENC_STUFF_GRID.)

@@ -263,66 +263,160 @@ __device__ __forceinline__ void load_token_templates(const u32* __restrict__ ima
 // walking twice -- once for the length, once for the bits -- does everything twice.  Here a
 // lane turns its block's 64 coefficients into 64 tokens (template | amplitude bits, length in
 // bits 31..27, 0 for a zero coefficient) without a branch, keeps them in registers, and the
-// second pass only puts them where they belong.  Runs of sixteen zeros and more in front of a
-// coefficient (ZRL symbols, Encoder.cpp:318-328) are not coded here: `longRuns` tells that the block
-// has one, and the caller takes the general walk for it.
+// second pass only puts them where they belong.
+//
+// The kernel is bound by the number of vector instructions, so the look-up is arranged to need
+// few: the templates of a table lie in rows of kTabPitch words per run, 63 rows (a run of 16 and
+// more, for which the stream wants ZRL symbols (Encoder.cpp:318-328) that this pass does not write,
+// finds kTokAbsent there, like a symbol without a code: the caller takes the general walk for
+// the tile then).  The lane carries 63 minus the index of its last non-zero coefficient; coefficient
+// i reads row (that + i - 64), the constant part of which sits in the instruction's offset
+// field, and a non-zero coefficient replaces the number by a constant.  Eleven instructions
+// per coefficient.
+constexpr int kDenseRows = 63;
+constexpr int kDenseAcWords = kDenseRows * kTabPitch;
+
+struct DenseTables {
+    u32 ac[2 * kDenseAcWords];   // luma, chroma: [run][category], column 0 (a zero coefficient) empty
+    u32 dc[32];                  // luma, chroma: [category]
+    u32 eob[2];
+    // Bits a coefficient of a category costs behind a run of zeros, ZRL symbols for runs of sixteen and
+    // more included (Encoder.cpp:318-328), laid out like `ac`; kDenseNoCode when a symbol it needs has no code.
+    unsigned short acBits[2 * kDenseAcWords];
+};
+constexpr u32 kDenseNoCode = 0x4000u;   // (as kNoCodeLength: no block has that many bits)
+
+// The templates of a table image (kernels.h) into LDS, by the 256 threads of a workgroup; the caller
+// passes a barrier afterwards.
+__device__ __forceinline__ void load_dense_tables(const u32* __restrict__ image, DenseTables& t) {
+    for (int i = threadIdx.x; i < 2 * kDenseAcWords; i += 256) {
+        const int c = i >= kDenseAcWords ? 1 : 0, rem = i - c * kDenseAcWords;
+        const int row = rem / kTabPitch, col = rem - row * kTabPitch;
+        t.ac[i] = row < 16 ? image[kTabTemplates + c * kTabAcWords + rem] : (col == 0 ? 0u : kTokAbsent);
+    }
+    if (threadIdx.x < 32) t.dc[threadIdx.x] = image[kTabTemplates + kTabDc + threadIdx.x];
+    if (threadIdx.x < 2) t.eob[threadIdx.x] = image[kTabTemplates + kTabEob + threadIdx.x];
+    for (int i = threadIdx.x; i < 2 * kDenseAcWords; i += 256) {
+        const int c = i >= kDenseAcWords ? 1 : 0, rem = i - c * kDenseAcWords;
+        const int row = rem / kTabPitch, col = rem - row * kTabPitch;
+        const u32* acTable = image + (2 + c) * 256;   // length << 16 | code, by symbol
+        const u32 symLen = acTable[((row & 15) << 4) | (col & 15)] >> 16, zrlLen = acTable[0xF0] >> 16;
+        u32 bits = symLen + (u32)col + (u32)(row >> 4) * zrlLen;
+        if (symLen == 0 || (row >= 16 && zrlLen == 0)) bits = kDenseNoCode;
+        t.acBits[i] = (unsigned short)(col == 0 ? 0u : bits);
+    }
+}
+
 struct DenseBlock {
     u32 tok[64];    // [0] the DC token, [i] coefficient i's, 0 for zero coefficients
     u32 eob;        // the end-of-block token, 0 when coefficient 63 is not zero (Encoder.cpp:343-347)
     u32 bits;       // length of the block's bit string
-    u32 maxTok;     // >= kTokAbsent: a symbol without a code
-    u32 longRuns;   // != 0: a non-zero coefficient follows sixteen zeros or more
+    u32 maxTok;     // >= kTokAbsent: a symbol without a code, or a run of sixteen zeros and more
 };
 
-__device__ __forceinline__ void dense_tokens(const u32 (&w)[32], int pred, const u32* tab, u32 chroma, DenseBlock& d) {
-    const char* acRows = (const char*)tab + chroma * (kTabAcWords * 4u);
+// Coefficients kFirst .. kFirst + kCount - 1 of a block (kFirst even; not the DC term): their look-ups
+// are all on their way before the first token is put together (one at a time every look-up is
+// waited for alone), and what they add to the sums is added there and then.  (The tokens are not
+// used before the second pass; left alone the compiler sinks their assembly and the sums down to
+// there and keeps template, category and coefficient of all 63 alive instead.)
+// back: 63 - (index of the last non-zero coefficient).
+template <int kFirst, int kCount>
+__device__ __forceinline__ void dense_batch(const u32 (&w)[32], const char* rows, u32 chromaAt, DenseBlock& d, u32& bits,
+                                            u32& maxTok, u32& back) {
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    u32 e[kCount], cat[kCount], amp[kCount / 2];
+#pragma unroll
+    for (int k = 0; k < kCount / 2; ++k) {   // v for v >= 0, v - 1 (the one's complement of |v|) for v < 0, Encoder.cpp:281-284
+        const s2 v = __builtin_bit_cast(s2, w[(kFirst >> 1) + k]);
+        amp[k] = __builtin_bit_cast(u32, (s2)(v + (v >> 15)));
+    }
+#pragma unroll
+    for (int k = 0; k < kCount; ++k) {
+        const int i = kFirst + k;
+        if (i == 0) continue;
+        const int v = (int)(short)(w[i >> 1] >> (16 * (i & 1)));
+        cat[k] = (u32)__builtin_amdgcn_frexp_expf((float)v);   // 0 for 0
+        // row (i - 1 - last) = back + i - 64, column cat
+        u32 at;   // back * pitch + (cat << 2) + chromaAt in two instructions (the compiler makes three of them)
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(at) : "v"(back), "s"((u32)(kTabPitch * 4)), "v"((cat[k] << 2) + chromaAt));
+        e[k] = *(const u32*)(rows + at + (i - 64) * (kTabPitch * 4));
+        back = cat[k] != 0 ? (u32)(63 - i) : back;
+    }
+#pragma unroll
+    for (int k = 0; k < kCount; ++k) {
+        const int i = kFirst + k;
+        if (i == 0) continue;
+        const u32 t = e[k] | __builtin_amdgcn_ubfe(amp[k >> 1], 16u * (i & 1), cat[k]);
+        d.tok[i] = t;
+        bits += t >> 27;
+        maxTok = max(maxTok, t);
+    }
+    asm volatile("" : "+v"(bits), "+v"(maxTok), "+v"(back));
+#pragma unroll
+    for (int k = 0; k < kCount; ++k)
+        if (kFirst + k != 0) asm volatile("" : "+v"(d.tok[kFirst + k]));
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void dense_tokens(const u32 (&w)[32], int pred, const DenseTables& tab, u32 chroma, DenseBlock& d) {
     {   // Encoder.cpp:268-284: the DC term's difference, its category, its amplitude bits
         const int diff = (int)(short)(w[0] & 0xffffu) - pred;
         const int cat = __builtin_amdgcn_frexp_expf((float)diff);
-        const u32 e = tab[kTabDc + chroma * 16u + (u32)cat];
+        const u32 e = tab.dc[chroma * 16u + (u32)cat];
         d.tok[0] = e | __builtin_amdgcn_ubfe((u32)(diff + (diff >> 31)), 0u, (u32)cat);
     }
-    u32 bits = d.tok[0] >> 27, maxTok = d.tok[0], longRuns = 0;
-    int last = 0;   // index of the last non-zero coefficient (the DC term counts, Encoder.cpp:304-306)
-    // Eight coefficients at a time: their look-ups are all on their way before the first token is put
-    // together (one at a time every look-up is waited for alone), and what a batch adds to the sums is
-    // added there and then.  (The tokens are not used before the second pass; left alone the compiler sinks
-    // their assembly and the sums down to there and keeps template, category, run and coefficient of all 63
-    // alive instead: three hundred registers.)
+    u32 bits = d.tok[0] >> 27, maxTok = d.tok[0];
+    u32 back = 63;   // (the DC term counts as the last non-zero coefficient, Encoder.cpp:304-306)
+    const char* rows = (const char*)tab.ac;
+    const u32 chromaAt = chroma * (u32)(kDenseAcWords * 4);
+    dense_batch<0, 8>(w, rows, chromaAt, d, bits, maxTok, back);
+    dense_batch<8, 8>(w, rows, chromaAt, d, bits, maxTok, back);
+    dense_batch<16, 8>(w, rows, chromaAt, d, bits, maxTok, back);
+    dense_batch<24, 8>(w, rows, chromaAt, d, bits, maxTok, back);
+    dense_batch<32, 8>(w, rows, chromaAt, d, bits, maxTok, back);
+    dense_batch<40, 8>(w, rows, chromaAt, d, bits, maxTok, back);
+    dense_batch<48, 8>(w, rows, chromaAt, d, bits, maxTok, back);
+    dense_batch<56, 8>(w, rows, chromaAt, d, bits, maxTok, back);
+    d.eob = back != 0 ? tab.eob[chroma] : 0u;
+    d.bits = bits + (d.eob >> 27);
+    d.maxTok = max(maxTok, d.eob);
+}
+
+// The length of a block's bit string alone, long runs of zeros included, with the same arithmetic
+// (for the tiles dense_tokens cannot code; what walk_block with a LengthVisitor finds).
+__device__ __forceinline__ u32 dense_lengths(const u32 (&w)[32], int pred, const DenseTables& tab, u32 chroma) {
+    u32 bits;
+    {
+        const int diff = (int)(short)(w[0] & 0xffffu) - pred;
+        const int cat = __builtin_amdgcn_frexp_expf((float)diff);
+        const u32 e = tab.dc[chroma * 16u + (u32)cat];
+        bits = e >= kTokAbsent ? kDenseNoCode : e >> 27;
+    }
+    u32 back = 63;
+    const char* rows = (const char*)tab.acBits;
+    const u32 chromaAt = chroma * (u32)(kDenseAcWords * 2);
 #pragma unroll
     for (int i0 = 0; i0 < 64; i0 += 8) {
-        u32 e[8], amp[8], cat[8];
+        u32 e[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int i = i0 + k;
             if (i == 0) continue;
             const int v = (int)(short)(w[i >> 1] >> (16 * (i & 1)));
-            cat[k] = (u32)__builtin_amdgcn_frexp_expf((float)v);   // 0 for 0
-            const u32 run = (u32)(i - 1 - last);
-            last = v != 0 ? i : last;
-            longRuns += (run & 0x30u) * cat[k];
-            e[k] = *(const u32*)(acRows + (run & 15u) * (kTabPitch * 4u) + (cat[k] << 2));   // column 0: empty
-            amp[k] = (u32)(v + (v >> 31));
+            const u32 cat = (u32)__builtin_amdgcn_frexp_expf((float)v);
+            const u32 at = back * (u32)(kTabPitch * 2) + ((cat << 1) + chromaAt);
+            e[k] = *(const unsigned short*)(rows + at + (i - 64) * (kTabPitch * 2));
+            back = cat != 0 ? (u32)(63 - i) : back;
         }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i = i0 + k;
-            if (i == 0) continue;
-            const u32 t = e[k] | __builtin_amdgcn_ubfe(amp[k], 0u, cat[k]);
-            d.tok[i] = t;
-            bits += t >> 27;
-            maxTok = max(maxTok, t);
-        }
-        asm volatile("" : "+v"(bits), "+v"(maxTok), "+v"(longRuns), "+v"(last));
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if (i0 + k != 0) asm volatile("" : "+v"(d.tok[i0 + k]));
-        __builtin_amdgcn_sched_barrier(0);
+            if (i0 + k != 0) bits += e[k];
     }
-    d.eob = last != 63 ? tab[kTabEob + chroma] : 0u;
-    d.bits = bits + (d.eob >> 27);
-    d.maxTok = max(maxTok, d.eob);
-    d.longRuns = longRuns;
+    if (back != 0) {
+        const u32 e = tab.eob[chroma];
+        bits += e >= kTokAbsent ? kDenseNoCode : e >> 27;
+    }
+    return bits;
 }
 
 // ORs the block's tokens into the (zeroed) stage in LDS, the first at bit position pos (counted
@@ -331,12 +425,14 @@ __device__ __forceinline__ void dense_put(const DenseBlock& d, u32* stage, u32 p
 #pragma unroll
     for (int i = 0; i < 65; ++i) {
         const u32 t = i < 64 ? d.tok[i] : d.eob;
-        const u32 len = t >> 27, sh = pos & 31u;
-        const u64 v = (u64)(t & 0x07ffffffu) << ((64u - sh - len) & 63u);   // (nothing to shift when len == 0)
+        // The token's bits end at bit `end` of the stream, i.e. 64 - (pos & 31) - len bits above the bottom of
+        // the two words at pos >> 5; the shift takes its amount modulo 64.  (Nothing to shift when len == 0.)
+        const u32 end = pos + (t >> 27);
+        const u64 v = (u64)(t & 0x07ffffffu) << (((pos & 32u) - end) & 63u);
         u32* at = stage + (pos >> 5);
         atomicOr(at, (u32)(v >> 32));
         atomicOr(at + 1, (u32)v);
-        pos += len;
+        pos = end;
         if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -1041,11 +1137,14 @@ __global__ __launch_bounds__(256) void k_place_tiles(KGeom g, const u64* __restr
 // The stream words at the edges of the tiles' parts: entries with the same word number are
 // ORed together (neighbours meet inside a word) and the first of such a run writes the word.
 // A band that does not begin the image starts with the RSTn of the interval in front of it.
-__global__ __launch_bounds__(256) void k_merge_edges(KGeom g, const u32* __restrict__ slots, u32* __restrict__ words, u32 tiles,
-                                                     u32* __restrict__ ffCount) {
-    const long long n = 4ll * tiles;
+__global__ __launch_bounds__(256) void k_merge_edges(KGeom g, const u32* __restrict__ list, u32 strideWords, u32 perTileLog2,
+                                                     u32* __restrict__ words, u32 tiles, u32* __restrict__ ffCount) {
+    // list: the first tile's entries; a tile has 1 << perTileLog2 of them, strideWords 32-bit words behind the tile's in front.
+    const long long n = (long long)tiles << perTileLog2;
     const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
-    auto entry = [&](long long k) { return ((const u64*)(slots + (size_t)(k >> 2) * kGrpSlotWords + kGrpSlotEdges))[k & 3]; };
+    auto entry = [&](long long k) {
+        return ((const u64*)(list + (size_t)(k >> perTileLog2) * strideWords))[k & ((1u << perTileLog2) - 1u)];
+    };
     if (c == 0 && interval_marker_bytes(g, 0) != 0) {
         // bits 31..16 of word 0; the first tile's first entry, if it lies in word 0 too, brings the rest
         u32 v = __builtin_bswap32((0xffd0u + (u32)((g.firstInterval - 1) & 7)) << 16);
