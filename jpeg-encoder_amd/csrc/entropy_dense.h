@@ -25,6 +25,9 @@
 //    with its neighbours, go to a list (two entries per tile) that k_merge_edges turns into stream
 //    words afterwards, everything in between is written with plain stores: the stream need not be
 //    cleared beforehand (8192 x 8192 4:4:4 noise: 196 MB, 28 us).
+#ifndef JPEGENC_DENSE_LOOK
+#define JPEGENC_DENSE_LOOK 1   // tiles per lane and step of the look-back
+#endif
 constexpr int kDenseStageWords = 6144;   // up to 96 bytes per block on average
 
 // Copies nOut words to the stream, from word w0 on: the stage's bits shifted right by s (0..31; word
@@ -224,6 +227,10 @@ void k_encode_dense(KGeom g, const int16_t* __restrict__ coef, const u32* __rest
         u64 start = p0;
         bool ok = true;
         if (tile > 0) ok = look_back(state, tile, p0, start);
+        // (Everything this wave has asked memory for is here: its look-back's answers came behind the next tile's
+        // coefficients.  Said explicitly, or the compiler, which cannot tell whether the look-back's last poll is
+        // still in flight, makes all four waves wait for their coefficients before they copy the tile out.)
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
         if (lane == 0) {
             if (!ok) {
                 start = p0;
