@@ -210,7 +210,7 @@ void k_encode_dense(KGeom g, const int16_t* __restrict__ coef, const u32* __rest
     __syncthreads();
     u32 tile = (u32)__builtin_amdgcn_readfirstlane(sh.ticket[0]);
     u32 parity = 0;
-    // The coefficients of the lane's block in the tile at hand, asked for while the tile before was copied out.
+    // The coefficients of the lane's block in the tile at hand, asked for a tile ahead.
     // (Asked for at one place in the loop and without conditions -- a ticket behind the last tile reads the
     // last tile again, lanes behind the image's end its last block: with several places, or a path on which
     // the registers keep their old values, the compiler keeps copies of all 32 alive round the loop and spills.)
@@ -222,14 +222,14 @@ void k_encode_dense(KGeom g, const int16_t* __restrict__ coef, const u32* __rest
         load_block(g, coef, b, w);
         fetchedDc = load_dc(g, coef, dc_predictor_source(l.role, b));
     };
-    // The tile's start from the tiles in front of it, and its end for those behind; by wave 0.
-    auto find_start = [&](PosSummary whole) {
+    // A tile's start from the tiles in front of it, and its end for those behind; by wave 0.
+    auto find_start = [&](u32 which, PosSummary whole) {
         u64 start = p0;
         bool ok = true;
-        if (tile > 0) ok = look_back(state, tile, p0, start);
-        // (Everything this wave has asked memory for is here: its look-back's answers came behind the next tile's
-        // coefficients.  Said explicitly, or the compiler, which cannot tell whether the look-back's last poll is
-        // still in flight, makes all four waves wait for their coefficients before they copy the tile out.)
+        if (which > 0) ok = look_back(state, which, p0, start);
+        // (Everything this wave has asked memory for is here.  Said explicitly, or the compiler, which cannot
+        // tell whether the look-back's last poll is still in flight, makes all four waves wait for whatever they
+        // have in flight before they copy a tile out.)
         __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
         if (lane == 0) {
             if (!ok) {
@@ -237,20 +237,47 @@ void k_encode_dense(KGeom g, const int16_t* __restrict__ coef, const u32* __rest
                 atomicOr((unsigned long long*)&result[1], 2ull);
                 if (hostResult) hostResult[2] = 2;
             }
-            __hip_atomic_store(state + tile, kTilePosition | pos_apply(whole, start), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(state + which, kTilePosition | pos_apply(whole, start), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sh.tileStart = start;
         }
         return start;
     };
+    // The tile whose bits wait in the stage: a tile is copied out while the next one's tokens sit in registers,
+    // a tile's time after it has reported its length.  A tile waits for the tiles in front of it to report theirs,
+    // and of a thousand tiles in flight some are always late: looked for right after its own bits were staged, a
+    // tile's start cost ten polls of the states in front, each a round trip to memory.
+    u32 heldTile = 0, heldBits = 0;
+    u64 heldStart = 0;
+    int held = 0;   // 0: none, 1: staged from bit 0, start yet to be found, 2: staged where it goes (from heldStart & ~31 on)
+    auto copy_out_held = [&]() {   // by the whole workgroup; passes a barrier if the start has to be found
+        if (held == 1) {
+            if (wave == 0) find_start(heldTile, PosSummary{heldBits, 0u});
+            lds_barrier();
+            heldStart = sh.tileStart;
+        }
+        if (held != 0) {
+            const u64 firstWord = heldStart >> 5;
+            const u32 nOut = (u32)(((heldStart + heldBits + 31) >> 5) - firstWord);
+            u64* myEdges = edges + 2ull * heldTile;
+            if ((long long)((firstWord + nOut) * 4) <= streamBytes) {
+                dense_copy_out(sh.stage, nOut, (u32)(heldStart & 31), firstWord, words, ffCount, myEdges);
+            } else if (threadIdx.x == 0) {
+                myEdges[0] = myEdges[1] = kNoEdge;
+                atomicOr((unsigned long long*)&result[1], 4ull);
+            }
+        }
+        held = 0;
+    };
     fetch_tile(tile);
+    // The number of the tile after this one: one request is on its way at any time, asked for when the one before
+    // is taken up (what is asked for is waited for where it is first used; the counter is one address for a thousand
+    // workgroups, and an answer takes microseconds).
+    u32 myTicket = 0;
+    if (threadIdx.x == 0) myTicket = (u32)atomicAdd((unsigned long long*)counter, 1ull);
     while (tile < tiles) {
         // (What was worked out about this tile when its coefficients were asked for is worked out again
         // rather than kept in registers all the way round the loop: the number is made opaque here.)
         asm volatile("" : "+s"(tile));
-        // The next tile's number: asked for now, put where all can read it further down (what is asked
-        // for is waited for where it is first used).
-        u32 myTicket = 0;
-        if (threadIdx.x == 0) myTicket = (u32)atomicAdd((unsigned long long*)counter, 1ull);
         const u32 image = g.batch > 1 ? tile / tilesPerImage : 0u;
         if (image != stagedImage) {   // (batches: the tile's image has tables of its own)
             stage_tables(tables + (long long)image * g.tableStride);
@@ -270,6 +297,7 @@ void k_encode_dense(KGeom g, const int16_t* __restrict__ coef, const u32* __rest
         }
         // A run of sixteen zeros or more, or a symbol without a code, somewhere in the tile: see below.
         if (__ballot(active && dense.maxTok >= kTokAbsent) != 0 && lane == 0) sh.surprise = 1;
+        if (threadIdx.x == 0) sh.ticket[parity ^ 1u] = myTicket;
         {
             const u32 inc = wave_scan_add(bits);
             if (lane == 63) sh.waveSum[wave].x = inc;
@@ -283,15 +311,21 @@ void k_encode_dense(KGeom g, const int16_t* __restrict__ coef, const u32* __rest
             }
             offset = before + inc - bits;
         }
+        const u32 next = (u32)__builtin_amdgcn_readfirstlane(sh.ticket[parity ^ 1u]);
+        parity ^= 1u;
+        if (threadIdx.x == 0) myTicket = (u32)atomicAdd((unsigned long long*)counter, 1ull);
         const bool surprise = sh.surprise != 0;
         const bool general = surprise || dense_boundary_tile(g, tile, tilesPerImage) ||
                              ((total + 31u) >> 5) + 2u > (u32)kDenseStageWords;
-        // Where the tile's staged bits go when it is copied out (tiles that are not listed).
-        u64 outStart = 0;
-        u32 outBits = total;
-        bool listed = false;
+        if (!general && threadIdx.x == 0 && tile > 0)
+            __hip_atomic_store(state + tile, kTileAggregate | ((u64)total << 30), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The tile before goes out now, and the stage is free for this one.
+        copy_out_held();
+        // The next tile's coefficients are asked for here, and arrive while this tile's bits are staged.
+        fetch_tile(next);
+        lds_barrier();   // the stage is free, and everybody has seen the flag and read the sums
+        if (threadIdx.x == 0) sh.surprise = 0;
         if (general) {
-            lds_barrier();   // (everybody has seen the flag and read the sums)
             PosSummary mine = {0u, 0u};
             long long iv = 0;
             bool firstOfInterval = false, lastOfInterval = false, lastOfAll = false, lastOfImage = false;
@@ -302,6 +336,11 @@ void k_encode_dense(KGeom g, const int16_t* __restrict__ coef, const u32* __rest
                 asm volatile("" : "+v"(thread));
                 const DenseLane me = dense_lane(g, tile, tilesPerImage, thread);
                 if (surprise) {   // lengths once more, by the look-up that knows long runs
+                    // (The tile goes on the list and its tokens are not used again.  The compiler cannot see that:
+                    // giving them a value here ends the life of 65 registers where 32 more are wanted.)
+#pragma unroll
+                    for (int i = 0; i < 64; ++i) dense.tok[i] = 0;
+                    dense.eob = 0;
                     u32 again[32];
                     const long long b = me.active ? me.b : (long long)me.image * g.blocksPerImage + g.blocksPerImage - 1;
                     load_block(g, coef, b, again);
@@ -341,13 +380,14 @@ void k_encode_dense(KGeom g, const int16_t* __restrict__ coef, const u32* __rest
             }
             // Listed: the general walk has to write the tile (k_encode_dense_rest).  Otherwise its tokens are
             // at hand, and go to the stage once the tile's start is known: where the padding in front of a
-            // boundary falls, and the interval offsets in bytes, depend on it.
-            listed = surprise || (((whole.x & 0x7fffffffu) + whole.y + 64u + 31u) >> 5) + 2u > (u32)kDenseStageWords;
+            // boundary falls, and the interval offsets in bytes, depend on it.  Either way the start is found
+            // here and now.
+            const bool listed = surprise || (((whole.x & 0x7fffffffu) + whole.y + 64u + 31u) >> 5) + 2u > (u32)kDenseStageWords;
             if (wave == 0) {
                 if (tile > 0 && lane == 0)
                     __hip_atomic_store(state + tile, kTileAggregate | ((u64)whole.x << 30) | whole.y, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
-                const u64 start = find_start(whole);
+                const u64 start = find_start(tile, whole);
                 if (listed && lane == 0) {
                     const u64 at = atomicAdd((unsigned long long*)dense_list_count(state, tiles), 1ull);
                     dense_list(state, tiles)[at] = (start << kDenseListTileBits) | tile;
@@ -397,9 +437,11 @@ void k_encode_dense(KGeom g, const int16_t* __restrict__ coef, const u32* __rest
                 if (active && (threadIdx.x == kEntThreads - 1 || lastOfImage)) sh.span[1] = pos + bits + (u32)padBits + (tailEoi ? 16u : 0u);
                 lds_barrier();
                 const u64 origin = sh.span[0] & ~31ull;
-                outStart = origin;
-                outBits = (u32)(sh.span[1] - origin);
-                for (u32 i = threadIdx.x; i < ((outBits + 31u) >> 5) + 2u; i += kEntThreads) sh.stage[i] = 0;
+                heldTile = tile;
+                heldStart = origin;
+                heldBits = (u32)(sh.span[1] - origin);
+                held = 2;
+                for (u32 i = threadIdx.x; i < ((heldBits + 31u) >> 5) + 2u; i += kEntThreads) sh.stage[i] = 0;
                 lds_barrier();
                 if (active) {
                     const u32 at = (u32)(pos - origin);
@@ -416,42 +458,18 @@ void k_encode_dense(KGeom g, const int16_t* __restrict__ coef, const u32* __rest
                 }
             }
         } else {
-            if (threadIdx.x == 0 && tile > 0)
-                __hip_atomic_store(state + tile, kTileAggregate | ((u64)total << 30), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u32 nStage = ((total + 31u) >> 5) + 2u;   // (a token's second word may be the one behind the last)
             for (u32 i = threadIdx.x; i < nStage; i += kEntThreads) sh.stage[i] = 0;
             lds_barrier();
             if (active) dense_put(dense, sh.stage, offset);
+            heldTile = tile;
+            heldBits = total;
+            held = 1;
         }
-        if (threadIdx.x == 0) {
-            sh.ticket[parity ^ 1u] = myTicket;
-            sh.surprise = 0;
-        }
-        lds_barrier();   // the stage is complete, and the next ticket has long arrived
-        const u32 next = (u32)__builtin_amdgcn_readfirstlane(sh.ticket[parity ^ 1u]);
-        parity ^= 1u;
-        // The next tile's coefficients are asked for here, and arrive while this tile finds its start and its
-        // words go out.  (Loads return in order: the look-back's first answer comes behind these.)
-        fetch_tile(next);
-        if (!general) {
-            if (wave == 0) find_start(PosSummary{total, 0u});
-            lds_barrier();
-            outStart = sh.tileStart;
-        }
-        if (!listed) {
-            const u64 firstWord = outStart >> 5;
-            const u32 nOut = (u32)(((outStart + outBits + 31) >> 5) - firstWord);
-            u64* myEdges = edges + 2ull * tile;
-            if ((long long)((firstWord + nOut) * 4) <= streamBytes) {
-                dense_copy_out(sh.stage, nOut, (u32)(outStart & 31), firstWord, words, ffCount, myEdges);
-            } else if (threadIdx.x == 0) {
-                myEdges[0] = myEdges[1] = kNoEdge;
-                atomicOr((unsigned long long*)&result[1], 4ull);
-            }
-        }
-        lds_barrier();   // the stage is free again
+        lds_barrier();   // the stage is complete
         tile = next;
     }
+    copy_out_held();
 }
 
 // The tiles k_encode_dense has left to the general walk: their bits, at the starts the list gives.
