@@ -1418,8 +1418,8 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
                            ws.tileState, ws.ivOff, ws.result, (u32*)ws.unstuffed, ws.groupTile, zero, ws.tileSlots, nullptr);
         const u32 runs = (u32)((tileCount + 63) / 64);
         u64* runStart = ws.tileState + tileCount;   // (the buffer is sized for tiles of 16 blocks)
-        hipLaunchKernelGGL(k_tile_positions, dim3(runs), dim3(64), 0, s, g, ws.tileState, runStart, (u32)tileCount,
-                           runStart + runs);   // (a word the clearing kernel has zeroed)
+        hipLaunchKernelGGL(k_tile_positions, dim3((runs + kPositionRunsPerWave - 1) / kPositionRunsPerWave), dim3(64), 0, s, g,
+                           ws.tileState, runStart, (u32)tileCount, runStart + runs);   // (a word the clearing kernel has zeroed)
         hipLaunchKernelGGL(k_place_tiles, dim3((unsigned)((tileCount + 3) / 4)), dim3(256), 0, s, g, ws.tileState, runStart,
                            ws.tileSlots, ws.ivOff, ws.result, (u32*)ws.unstuffed, (u32)tileCount, zero, ws.ffCount);
         hipLaunchKernelGGL(k_merge_edges, dim3((unsigned)((4 * tileCount + 255) / 256)), dim3(256), 0, s, g,

@@ -1050,42 +1050,66 @@ __device__ __forceinline__ PosSummary wave_scan_summary(PosSummary inc) {
 // device scope writes a whole L2 back): a run's summary is put down with an exchange that
 // returns, so it has been performed when the wave counts itself off, and the last wave reads the
 // summaries where the exchanges were made.
+constexpr int kPositionRunsPerWave = 4;
 __global__ __launch_bounds__(64) void k_tile_positions(KGeom g, u64* __restrict__ summary, u64* __restrict__ runSummary,
                                                        u32 tiles, u64* __restrict__ done) {
+    // (A wave takes kPositionRunsPerWave runs: the count-off is one address for all waves, and additions to one
+    // address from all over the device are performed one behind the other, some twenty nanoseconds each.)
     const int lane = threadIdx.x;
-    const u32 t = blockIdx.x * 64u + (u32)lane;
-    const u64 v = t < tiles ? summary[t] : 0ull;
-    const PosSummary inc = wave_scan_summary(PosSummary{(u32)(v >> 32), (u32)v});
-    PosSummary excl;
-    excl.x = __shfl_up(inc.x, 1, 64);
-    excl.y = __shfl_up(inc.y, 1, 64);
-    if (lane == 0) excl.x = excl.y = 0;
-    if (t < tiles) summary[t] = ((u64)excl.x << 32) | excl.y;
+    const u32 runs = (tiles + 63u) / 64u;
+    u64 v[kPositionRunsPerWave];
+#pragma unroll
+    for (int k = 0; k < kPositionRunsPerWave; ++k) {
+        const u32 t = (blockIdx.x * (u32)kPositionRunsPerWave + (u32)k) * 64u + (u32)lane;
+        v[k] = t < tiles ? summary[t] : 0ull;
+    }
+    u64 old = 0;
+#pragma unroll
+    for (int k = 0; k < kPositionRunsPerWave; ++k) {
+        const u32 r = blockIdx.x * (u32)kPositionRunsPerWave + (u32)k;
+        const u32 t = r * 64u + (u32)lane;
+        const PosSummary inc = wave_scan_summary(PosSummary{(u32)(v[k] >> 32), (u32)v[k]});
+        PosSummary excl;
+        excl.x = __shfl_up(inc.x, 1, 64);
+        excl.y = __shfl_up(inc.y, 1, 64);
+        if (lane == 0) excl.x = excl.y = 0;
+        if (t < tiles) summary[t] = ((u64)excl.x << 32) | excl.y;
+        if (lane == 63 && r < runs) old |= atomicExch((unsigned long long*)&runSummary[r], ((u64)inc.x << 32) | inc.y);
+    }
     u64 seen = 0;
     if (lane == 63) {
-        const u64 old = atomicExch((unsigned long long*)&runSummary[blockIdx.x], ((u64)inc.x << 32) | inc.y);
-        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the exchange has been performed
-        // (the returned value is of no interest -- whatever the buffer held before -- but asking for it
-        // here keeps the exchange, and the wait for it, in front of the count-off)
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the exchanges have been performed
+        // (the returned values are of no interest -- whatever the buffer held before -- but asking for them
+        // here keeps the exchanges, and the wait for them, in front of the count-off)
         asm volatile("" : : "v"((u32)old), "v"((u32)(old >> 32)) : "memory");
         seen = atomicAdd((unsigned long long*)done, 1ull) + 1;
     }
     const u32 count = (u32)__builtin_amdgcn_readlane((u32)seen, 63);
     if (count != gridDim.x) return;
-    // Last wave: 64 runs at a time, the runs in front carried along.
-    const u32 runs = gridDim.x;
+    // Last wave: 64 runs at a time, the runs in front carried along.  The summaries of up to kAhead * 64 runs
+    // are asked for in one go (one round trip to memory instead of one per 64 runs: 16384 x 16384 4:2:0 has 384).
     const u64 p0 = 8ull * (u64)interval_marker_bytes(g, 0);
     PosSummary before = {0u, 0u};
-    for (u32 first = 0; first < runs; first += 64) {
-        const u32 r = first + (u32)lane;
-        const u64 w = r < runs ? __hip_atomic_load(&runSummary[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        const PosSummary in = wave_scan_summary(PosSummary{(u32)(w >> 32), (u32)w});
-        PosSummary ex;
-        ex.x = __shfl_up(in.x, 1, 64);
-        ex.y = __shfl_up(in.y, 1, 64);
-        if (lane == 0) ex.x = ex.y = 0;
-        if (r < runs) runSummary[r] = pos_apply(pos_combine(before, ex), p0);
-        before = pos_combine(before, PosSummary{(u32)__builtin_amdgcn_readlane(in.x, 63), (u32)__builtin_amdgcn_readlane(in.y, 63)});
+    constexpr int kAhead = 8;
+    for (u32 first = 0; first < runs; first += 64 * kAhead) {
+        u64 w[kAhead];
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) {
+            const u32 r = first + 64u * k + (u32)lane;
+            w[k] = r < runs ? __hip_atomic_load(&runSummary[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) {
+            if (first + 64u * k >= runs) break;
+            const u32 r = first + 64u * k + (u32)lane;
+            const PosSummary in = wave_scan_summary(PosSummary{(u32)(w[k] >> 32), (u32)w[k]});
+            PosSummary ex;
+            ex.x = __shfl_up(in.x, 1, 64);
+            ex.y = __shfl_up(in.y, 1, 64);
+            if (lane == 0) ex.x = ex.y = 0;
+            if (r < runs) runSummary[r] = pos_apply(pos_combine(before, ex), p0);
+            before = pos_combine(before, PosSummary{(u32)__builtin_amdgcn_readlane(in.x, 63), (u32)__builtin_amdgcn_readlane(in.y, 63)});
+        }
     }
 }
 
