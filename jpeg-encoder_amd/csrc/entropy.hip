@@ -1377,7 +1377,11 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     // is a longer chain than the image has work to hide (1080p: 37 -> 44 us).
     // (Diagnostic switch JPEGENC_GROUP_MIN_BLOCKS: another threshold, e.g. 0 to test it on small images.)
     const long long minBlocks = group_min_blocks();
-    const bool groups = ws.groupTile > 0 && !old_entropy_kernels() && g.totalBlocks >= minBlocks &&
+    // (Diagnostic switch JPEGENC_WRITER=dense: the writer for long blocks whatever the content; read at every call so
+    // that a test can set it.)
+    const char* writer = getenv("JPEGENC_WRITER");
+    const bool forceDense = writer != nullptr && writer[0] == 'd';
+    const bool groups = ws.groupTile > 0 && !old_entropy_kernels() && !forceDense && g.totalBlocks >= minBlocks &&
                         (g.intervals == g.batch || g.mcusPerInterval * g.bpm >= kGrpMinIntervalBlocks);
     const long long tilesPerImage = groups ? group_tiles_per_image(g.blocksPerImage, ws.groupTile)
                                            : (g.blocksPerImage + kEntThreads - 1) / kEntThreads;
@@ -1389,7 +1393,7 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     // word of the stream exactly once, with plain stores.)
     const bool deferred = groups && ws.tileSlots != nullptr && ws.groupTile == kGrpTileBlocks;
     // The kernels that write the stream keep the per-chunk counts of its 0xFF bytes.
-    const bool shortBlocks = ws.avgBlockBits <= 128;   // long blocks (noise, q=100) do not fit the private words; unknown lengths count as short
+    const bool shortBlocks = ws.avgBlockBits <= 128 && !forceDense;   // long blocks (noise, q=100) do not fit the private words; unknown lengths count as short
     const bool dense = !groups && !shortBlocks;   // (k_encode_dense writes every word once as well)
     const long long clear16 = deferred || dense ? 0 : zero / 16;
     // Chunks the stream can have at most: from the bound that was cleared.

@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(64) void k_tile_positions(KGeom g, u64* __restrict_
 
 // Deferred placement (see k_encode_groups): one wave per tile; state[tile] holds the summary of the
 // tiles in front of it inside its run of 64, runStart the position at which the run starts
-// (k_group_positions, k_run_positions).
+// (k_tile_positions).
 __global__ __launch_bounds__(256) void k_place_tiles(KGeom g, const u64* __restrict__ state, const u64* __restrict__ runStart,
                                                      u32* __restrict__ slots, u64* __restrict__ ivOff, u64* __restrict__ result,
                                                      u32* __restrict__ words, u32 tiles, long long zeroedBytes,

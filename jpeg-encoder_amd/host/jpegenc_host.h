@@ -195,8 +195,9 @@ public:
     const_iterator begin() const { return const_iterator(codeMap.data(), codeMap.data() + 256); }
     const_iterator end() const { return const_iterator(codeMap.data() + 256, codeMap.data() + 256); }
 
-    // Package-merge table with a reserved all-ones code.  Only the JPEG limit of 16 bits is
-    // implemented (jpeg_hip_huffman_from_histogram); other limits return nullptr.
+    // Package-merge table with a reserved all-ones code (HuffmanCodingByte.h:102-210) for every limit the
+    // reference accepts: 16, the JPEG limit, through jpeg_hip_huffman_from_histogram; 9..64 through
+    // jpeg_hip_huffman_from_histogram_limit; above 64 and below 9 a null table, as there (:105, :121).
     static HuffmanTablePtr<byte> create(size_t codeWordLength, const std::vector<byte>& srcData);
     static HuffmanTablePtr<byte> fromLengthsAndCodes(const uint8_t lengths[256], const uint16_t codes[256]);
     BitBufferPtr encode(const std::vector<byte>& srcData);
