@@ -339,33 +339,10 @@ __device__ __forceinline__ u64 block_exclusive_scan(u64 v, u64* lds, u64& total)
     return base + inc - v;
 }
 
-// The same for a caller with loads in flight that the barriers must not wait for: the barriers
-// order the accesses to `lds` only (u32 values, a workgroup of 256).
+// A barrier for a caller with loads in flight that it must not wait for: it orders accesses to LDS only.
 __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the LDS accesses, not the loads from memory
     __builtin_amdgcn_s_barrier();
-}
-
-__device__ __forceinline__ u32 block_exclusive_scan_lds(u32 v, u32* lds, u32& total) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    u32 inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
-    }
-    lds_barrier();
-    if (lane == 63) lds[wave] = inc;
-    lds_barrier();
-    u32 base = 0, sum = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const u32 t = lds[i];
-        if (i < wave) base += t;
-        sum += t;
-    }
-    total = sum;
-    return base + inc - v;
 }
 
 // Per 4 KiB chunk of the unstuffed stream, ffCount holds the number of stuffing bytes the chunk
@@ -1117,6 +1094,27 @@ __device__ __forceinline__ long long batch_position(const BatchOutput& bo, const
 // which is what a long stream is bound by (16384 x 16384: 42.5 -> 38.8 us, 8192 x 8192 noise 4:4:4:
 // 133 -> 108 us), but a longer way through a single chunk (1080p: 6.9 -> 11.4 us), so short streams
 // keep the other form.
+// Exclusive scan of one value per thread over a workgroup of 256, the wave's part with row shifts and row
+// broadcasts (wave_scan_add) instead of six shuffles through the LDS crossbar, each of which is waited for:
+// the stuffing pass does one scan per 4 KiB chunk, one chunk behind the other.  lds: 4 values; the barriers
+// order the accesses to it only (the caller has loads in flight).
+__device__ __forceinline__ u32 block_exclusive_scan_dpp(u32 v, u32* lds, u32& total) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 inc = wave_scan_add(v);
+    lds_barrier();
+    if (lane == 63) lds[wave] = inc;
+    lds_barrier();
+    u32 base = 0, sum = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32 t = lds[i];
+        if (i < wave) base += t;
+        sum += t;
+    }
+    total = sum;
+    return base + inc - v;
+}
+
 template <bool kBatch, bool kOwnBytes>
 __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __restrict__ buf,
                                                      const u64* __restrict__ ivOff, const u32* __restrict__ ffCount,
@@ -1167,7 +1165,7 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
             mask = stuff_mask(g, buf, ivOff, bytes, i0, q, (flags & 1u) == 0);
         }
         u32 total;
-        const u32 local = block_exclusive_scan_lds((u32)(valid + __popc(mask)), scanLds, total);
+        const u32 local = block_exclusive_scan_dpp((u32)(valid + __popc(mask)), scanLds, total);
         // Output range of the chunk: one piece, except for a batch chunk that spans images.
         long long base, limit;
         bool onePiece = true;
