@@ -179,7 +179,11 @@ inline WorkspaceSizes workspace_sizes(const Geometry& g, int images, int64_t uns
     if (unstuffedLimit >= 0 && unstuffedLimit / 16 * 16 < w.unstuffedCap) w.unstuffedCap = unstuffedLimit / 16 * 16;
     w.maxChunks = (w.unstuffedCap + kStuffChunk - 1) / kStuffChunk;
     // One state word per tile of the bit writer; its smallest tiles are 16 blocks, in fours per image.
-    w.tiles = ((g.totalBlocks + 15) / 16 + 4) * images;
+    // (and room for what the dense bit writer keeps behind the states of its tiles of 256 blocks)
+    w.tiles = (g.totalBlocks + 15) / 16 * images;
+    const int64_t denseWords = dense_state_words((g.totalBlocks + 255) / 256 * images);
+    if (w.tiles < denseWords) w.tiles = denseWords;
+    w.tiles += 4 * images;
     w.coef = (size_t)nb * 128;
     w.gmask = (size_t)nb + 64;   // one byte per block, read in dwords
     w.qtab = sizeof(Pinned::qtab);

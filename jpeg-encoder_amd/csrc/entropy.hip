@@ -1407,8 +1407,8 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     // off with has to be zero.
     const long long deferredRuns = (tileCount + 63) / 64;
     u64* clearStates = deferred ? ws.tileState + tileCount + deferredRuns : ws.tileState;
-    // (k_encode_dense: the tiles' states, its ticket counter and the count of its list)
-    const long long clearStateWords = deferred ? 1 : tileCount + 2;
+    // (k_encode_dense: the tiles' states and the words behind them that start at zero)
+    const long long clearStateWords = deferred ? 1 : (dense ? dense_zeroed_words(tileCount) : tileCount + 2);
     hipLaunchKernelGGL(k_prepare_entropy, dim3((unsigned)prepGrid), dim3(256), 0, s, (uint4*)ws.unstuffed, clear16,
                        clearStates, clearStateWords, ws.result, ws.header, bo ? 0 : ws.headerLen, d_out,
                        bo ? nullptr : ws.pendingTables, const_cast<u32*>(d_tables), ws.ffCount, chunkBound);
@@ -1437,13 +1437,18 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
         // As many workgroups as the device holds at once (four per CU, by registers and LDS); each takes tile
         // after tile.  (Diagnostic switch JPEGENC_DENSE_GRID: another number.)
         static const long long denseGrid = getenv("JPEGENC_DENSE_GRID") ? atoll(getenv("JPEGENC_DENSE_GRID")) : 1024;
-        const unsigned grid = (unsigned)(tileCount < denseGrid ? tileCount : denseGrid);
+        unsigned grid = (unsigned)(tileCount < denseGrid ? tileCount : denseGrid);
+        grid = grid < 1u ? 1u : (grid > kDenseMaxGrid ? kDenseMaxGrid : grid);
+        // Tile numbers by XCD from three tiles per workgroup on (4096 x 4096 4:4:4, 3072 tiles: 72 against 84 us).
+        // (Diagnostic switch JPEGENC_DENSE_PER_XCD_FROM, read at every call so that a test can set it.)
+        const char* fromText = getenv("JPEGENC_DENSE_PER_XCD_FROM");
+        const long long perXcdFrom = fromText ? atoll(fromText) : 3072;
         hipLaunchKernelGGL(k_encode_dense, dim3(grid), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.tileState, ws.ivOff,
-                           ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult, zero, ws.ffCount);
+                           ws.result, (u32*)ws.unstuffed, bo ? nullptr : ws.hostResult, zero, ws.ffCount, tileCount >= perXcdFrom ? 1u : 0u);
         hipLaunchKernelGGL(k_encode_dense_rest, dim3(grid < 256u ? grid : 256u), dim3(kEntThreads), 0, s, g, d_coef, d_tables, ws.tileState, ws.ivOff,
                            ws.result, (u32*)ws.unstuffed, zero, ws.ffCount);
         hipLaunchKernelGGL(k_merge_edges, dim3((unsigned)((2 * tileCount + 255) / 256)), dim3(256), 0, s, g,
-                           (const u32*)(ws.tileState + tileCount + 2), 4u, 1u, (u32*)ws.unstuffed, (u32)tileCount, ws.ffCount);
+                           (const u32*)(ws.tileState + dense_zeroed_words(tileCount)), 4u, 1u, (u32*)ws.unstuffed, (u32)tileCount, ws.ffCount);
     }
     // As many workgroups as the device holds at once (five per CU): a workgroup's run of chunks is
     // one chain (a chunk's bytes are asked for while the chunk in front is worked on), a second

@@ -4,9 +4,8 @@
 // One lane per block, a tile is 256 consecutive blocks of one image, tiles chain with the
 // decoupled look-back (look_back), as in k_encode_bits.  What differs:
 //
-//  * A workgroup stays and takes tile after tile from the counter.  The tables are staged once,
-//    the ticket of the next tile is on its way while the current one is worked on, and the next
-//    tile's coefficients are asked for before the current tile's words are copied out, so the
+//  * A workgroup stays and takes tile after tile (dense_draw_ticket).  The tables are staged once, and
+//    the next tile's coefficients are asked for before the current tile's words are copied out, so the
 //    round trips to memory that start a tile are hidden behind the end of the one before.
 //  * A block's 64 coefficients become 64 tokens in registers without a branch (dense_tokens) and
 //    are ORed into the stage in LDS (dense_put).
@@ -165,13 +164,83 @@ __device__ __forceinline__ void dense_walk_lengths(const KGeom& g, const int16_t
     }
 }
 
-// Where the state words of the two kernels lie behind the tiles' own (`state`, [tiles]): the ticket
-// counter, the number of tiles on the list, two edge entries per tile (k_merge_edges), the list
-// (start position << 24 | tile).  The first two start at zero.
-__device__ __forceinline__ u64* dense_ticket(u64* state, u32 tiles) { return state + tiles; }
+// Where the state words of the two kernels lie behind the tiles' own (`state`, [tiles]); see kDenseHead.
+__device__ __forceinline__ u64* dense_counter(u64* state, u32 tiles) { return state + tiles; }
 __device__ __forceinline__ u64* dense_list_count(u64* state, u32 tiles) { return state + tiles + 1; }
-__device__ __forceinline__ u64* dense_edges(u64* state, u32 tiles) { return state + tiles + 2; }
-__device__ __forceinline__ u64* dense_list(u64* state, u32 tiles) { return state + 3ull * tiles + 2; }
+__device__ __forceinline__ u64* dense_xcd_counter(u64* state, u32 tiles, u32 xcd) { return state + tiles + 2 + xcd * kDenseXcdStride; }
+__device__ __forceinline__ u64* dense_xcd_chunks(u64* state, u32 tiles, u32 xcd) {
+    return state + tiles + kDenseHead + (u64)xcd * (u64)dense_chunks_per_xcd(tiles);
+}
+__device__ __forceinline__ u64* dense_edges(u64* state, u32 tiles) { return state + dense_zeroed_words(tiles); }
+__device__ __forceinline__ u64* dense_list(u64* state, u32 tiles) { return state + dense_zeroed_words(tiles) + 2ull * tiles; }
+
+// Tile numbers.  One counter for the whole device is one address that a thousand workgroups on eight XCDs add
+// to at the same moments, and an answer takes microseconds, which is why a workgroup had to ask a tile ahead --
+// and a tile asked for that early is started on out of turn, which the tiles behind it wait for.  So the
+// workgroups of an XCD count their tickets on a word of their own, whose answer is quick enough to be waited for
+// where the number is needed, and the XCD fetches tile numbers from the device's counter a chunk at a time:
+// ticket m is tile chunks[m / kDenseChunk] + m % kDenseChunk.  Who draws ticket 0 fetches the chunks the XCD's
+// workgroups start with and kDenseAhead more, who draws the first ticket of chunk j fetches chunk j + kDenseAhead
+// if it is not there from the start: just early enough (an XCD that holds many tiles which it is not yet working
+// on makes the other XCDs' tiles wait); a table entry is written once (valid bit | first tile).
+//   The look-back's wait ends because (1) chunks come from the device's counter in order; (2) an XCD's chunks
+// have growing numbers -- who fetches chunk k has seen chunk k - 1 in the table -- so that an XCD gives its tiles
+// out in growing order and a workgroup's tiles grow; (3) nobody waits for a tile between drawing a ticket and
+// doing the fetching that comes with it.  The smallest tile that nobody has drawn yet belongs to a chunk whose
+// fetcher holds a smaller tile and waits, at most, for tiles smaller still, all of them drawn by workgroups of
+// which the same is true: they all get on, draw again, and the XCD's tickets reach that tile.  A workgroup
+// leaves when its ticket is behind the last tile, and all tickets its XCD gives out from then on are.
+//   (Which XCD a workgroup runs on is read from the hardware register; nothing but the sharing depends on it.)
+__device__ __forceinline__ u32 this_xcd() {
+    return (u32)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (u32)(kDenseXcds - 1);   // HW_REG_XCC_ID, bits 3..0
+}
+constexpr u64 kChunkValid = 1ull << 63;
+
+// A table entry once it is valid; false: it never came (cannot happen: who writes it waits for nobody but
+// writers of earlier entries).
+__device__ __forceinline__ bool dense_await_chunk(const u64* entry, u64& value) {
+    for (int spins = 0; (value & kChunkValid) == 0; ++spins) {
+        if (spins > kLookBackSpins) return false;
+        __builtin_amdgcn_s_sleep(1);
+        value = __hip_atomic_load(entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return true;
+}
+
+// Draws a ticket of the XCD: the tile number, or ~0u and `failed`.  By one thread.  chunkRoom: entries of `chunks`;
+// atStart: chunks that the drawer of ticket 0 fetches (> kDenseAhead).
+__device__ __forceinline__ u32 dense_draw_ticket(u64* __restrict__ xcdCounter, u64* __restrict__ chunks, u32 chunkRoom,
+                                                 u64* __restrict__ counter, u32 atStart, bool& failed) {
+    const u64 m = atomicAdd((unsigned long long*)xcdCounter, 1ull);
+    const u64 j = m / kDenseChunk;
+    const u32 slot = (u32)(m % kDenseChunk);
+    if (j + kDenseAhead >= chunkRoom || atStart > chunkRoom) {
+        failed = true;
+        return ~0u;
+    }
+    u64 mine = __hip_atomic_load(chunks + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (m == 0) {
+        const u64 first = atomicAdd((unsigned long long*)counter, (unsigned long long)atStart * kDenseChunk);
+        for (u32 i = 0; i < atStart; ++i)
+            __hip_atomic_store(chunks + i, kChunkValid | (first + (u64)i * kDenseChunk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (u32)first;
+    }
+    if (slot == 0 && j + kDenseAhead >= atStart) {
+        const u64 k = j + kDenseAhead;
+        u64 before = __hip_atomic_load(chunks + k - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!dense_await_chunk(chunks + k - 1, before)) {
+            failed = true;
+            return ~0u;
+        }
+        const u64 first = atomicAdd((unsigned long long*)counter, (unsigned long long)kDenseChunk);
+        __hip_atomic_store(chunks + k, kChunkValid | first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!dense_await_chunk(chunks + j, mine)) {
+        failed = true;
+        return ~0u;
+    }
+    return (u32)mine + slot;
+}
 constexpr int kDenseListTileBits = 24;
 
 struct DenseShared {
@@ -184,21 +253,33 @@ struct DenseShared {
     u32 surprise;
 };
 
-// state: see dense_ticket.  streamBytes: size of the stream's buffer.
+// state: see kDenseHead.  streamBytes: size of the stream's buffer.  perXcd: tile numbers by dense_draw_ticket
+// (pictures of many tiles per workgroup), or straight from the device's counter (0): with few tiles, those an
+// XCD holds in hand would be missing on another, whose workgroups would leave early.
 __global__ __launch_bounds__(kEntThreads) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void k_encode_dense(KGeom g, const int16_t* __restrict__ coef, const u32* __restrict__ tables, u64* __restrict__ state,
                     u64* __restrict__ ivOff, u64* __restrict__ result, u32* __restrict__ words, u64* __restrict__ hostResult, long long streamBytes,
-                    u32* __restrict__ ffCount) {
+                    u32* __restrict__ ffCount, u32 perXcd) {
     __shared__ DenseShared sh;
     const u32 tilesPerImage = (u32)((g.blocksPerImage + kEntThreads - 1) / kEntThreads);
     const u32 tiles = tilesPerImage * (u32)g.batch;
-    u64* counter = dense_ticket(state, tiles);
     u64* edges = dense_edges(state, tiles);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const u64 p0 = 8ull * (u64)interval_marker_bytes(g, 0);
 
+    auto draw_ticket = [&]() {   // thread 0.  (Nothing of this is kept in registers between two tickets.)
+        if (perXcd == 0) return (u32)atomicAdd((unsigned long long*)dense_counter(state, tiles), 1ull);
+        const u32 xcd = this_xcd();
+        // (the chunks an XCD's workgroups start with, were they spread evenly over eight XCDs, and kDenseAhead more)
+        const u32 atStart = (gridDim.x / 8u + kDenseChunk - 1u) / kDenseChunk + kDenseAhead;
+        bool failed = false;
+        const u32 t = dense_draw_ticket(dense_xcd_counter(state, tiles, xcd), dense_xcd_chunks(state, tiles, xcd),
+                                        (u32)dense_chunks_per_xcd(tiles), dense_counter(state, tiles), atStart, failed);
+        if (failed) atomicOr((unsigned long long*)&result[1], 2ull);
+        return t;
+    };
     if (threadIdx.x == 0) {
-        sh.ticket[0] = (u32)atomicAdd((unsigned long long*)counter, 1ull);
+        sh.ticket[0] = draw_ticket();
         sh.surprise = 0;
     }
     auto stage_tables = [&](const u32* image) { load_dense_tables(image, sh.templates); };
@@ -269,11 +350,6 @@ void k_encode_dense(KGeom g, const int16_t* __restrict__ coef, const u32* __rest
         held = 0;
     };
     fetch_tile(tile);
-    // The number of the tile after this one: one request is on its way at any time, asked for when the one before
-    // is taken up (what is asked for is waited for where it is first used; the counter is one address for a thousand
-    // workgroups, and an answer takes microseconds).
-    u32 myTicket = 0;
-    if (threadIdx.x == 0) myTicket = (u32)atomicAdd((unsigned long long*)counter, 1ull);
     while (tile < tiles) {
         // (What was worked out about this tile when its coefficients were asked for is worked out again
         // rather than kept in registers all the way round the loop: the number is made opaque here.)
@@ -297,7 +373,8 @@ void k_encode_dense(KGeom g, const int16_t* __restrict__ coef, const u32* __rest
         }
         // A run of sixteen zeros or more, or a symbol without a code, somewhere in the tile: see below.
         if (__ballot(active && dense.maxTok >= kTokAbsent) != 0 && lane == 0) sh.surprise = 1;
-        if (threadIdx.x == 0) sh.ticket[parity ^ 1u] = myTicket;
+        // The next tile's number, as late as it can be drawn without the other waves waiting for it for long.
+        if (threadIdx.x == 0) sh.ticket[parity ^ 1u] = draw_ticket();
         {
             const u32 inc = wave_scan_add(bits);
             if (lane == 63) sh.waveSum[wave].x = inc;
@@ -313,7 +390,6 @@ void k_encode_dense(KGeom g, const int16_t* __restrict__ coef, const u32* __rest
         }
         const u32 next = (u32)__builtin_amdgcn_readfirstlane(sh.ticket[parity ^ 1u]);
         parity ^= 1u;
-        if (threadIdx.x == 0) myTicket = (u32)atomicAdd((unsigned long long*)counter, 1ull);
         const bool surprise = sh.surprise != 0;
         const bool general = surprise || dense_boundary_tile(g, tile, tilesPerImage) ||
                              ((total + 31u) >> 5) + 2u > (u32)kDenseStageWords;
@@ -486,12 +562,14 @@ void k_encode_dense_rest(KGeom g, const int16_t* __restrict__ coef, const u32* _
     const u32 tilesPerImage = (u32)((g.blocksPerImage + kEntThreads - 1) / kEntThreads);
     const u32 tiles = tilesPerImage * (u32)g.batch;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u64 listed = *dense_list_count(state, tiles);
+    u64 listed = *dense_list_count(state, tiles);
+    if (listed > tiles) listed = tiles;   // (nothing is read or written on the say-so of a count or an entry that cannot be)
     u32 stagedImage = ~0u;
     for (u64 at = blockIdx.x; at < listed; at += gridDim.x) {
         const u64 entry = dense_list(state, tiles)[at];
         const u32 tile = (u32)(entry & ((1u << kDenseListTileBits) - 1u));
         const u64 tileStart = entry >> kDenseListTileBits;
+        if (tile >= tiles) continue;
         const u32 image = g.batch > 1 ? tile / tilesPerImage : 0u;
         __syncthreads();   // (the tile before is done with tables and stage)
         if (image != stagedImage) {

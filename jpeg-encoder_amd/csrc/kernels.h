@@ -66,6 +66,24 @@ struct BatchOutput {
     unsigned long long* ffStart;   // [batch + 1]: stuffing bytes in front of each image's stream
 };
 
+// What the bit writer for dense content keeps behind the states of its `tiles` tiles of 256 blocks, in 64-bit
+// words: a head that starts at zero (the device's counter of tile numbers, the number of listed tiles, a ticket
+// counter per XCD, 128 bytes apart), a table of chunks of tile numbers per XCD (starts at zero as well), two edge
+// entries per tile, the list of tiles left to the second kernel.
+constexpr int kDenseXcds = 16;           // as many as the hardware register's field can name
+constexpr int kDenseXcdStride = 16;      // words between the ticket counters of two XCDs
+constexpr int kDenseHead = 2 + kDenseXcds * kDenseXcdStride;
+constexpr unsigned kDenseChunk = 32;     // tile numbers an XCD fetches from the device's counter at a time
+constexpr unsigned kDenseMaxGrid = 2048; // workgroups of the dense bit writer at most
+constexpr unsigned kDenseAhead = 1;      // chunks an XCD has in hand beyond the one its workgroups draw from (>= 1)
+// Chunks an XCD can come to fetch: every tile and every workgroup's last, unsuccessful ticket could be its own,
+// plus those fetched ahead.
+constexpr long long dense_chunks_per_xcd(long long tiles) {
+    return (tiles + kDenseMaxGrid) / kDenseChunk + kDenseMaxGrid / (8 * kDenseChunk) + kDenseAhead + 3;
+}
+constexpr long long dense_zeroed_words(long long tiles) { return tiles + kDenseHead + kDenseXcds * dense_chunks_per_xcd(tiles); }
+constexpr long long dense_state_words(long long tiles) { return dense_zeroed_words(tiles) + 3 * tiles; }
+
 // Device workspace of the entropy stage (all sizes fixed by the geometry).
 struct EntropyWorkspace {
     unsigned long long* ivOff;   // [intervals + 1]: byte offset of every interval in the unstuffed stream
@@ -77,7 +95,7 @@ struct EntropyWorkspace {
     uint8_t* unstuffed;          // [unstuffedCap]
     long long unstuffedCap;
     long long maxChunks;
-    unsigned long long* tileState;   // [tiles + 1] of the single-pass bit writer (tiles of 256 blocks)
+    unsigned long long* tileState;   // [tiles + 1] of the single-pass bit writer (tiles of 256 blocks); dense_state_words
     long long streamBound;           // upper bound of the unstuffed stream in bytes, or < 0 when unknown
     long long avgBlockBits;          // mean entropy-coded bits per block according to the histograms, or < 0 when unknown
     int groupTile;                   // blocks per tile of the bit writer on groups: 256, 64 or 16; 0: the one-lane-per-block writer

@@ -14,9 +14,13 @@ from jpegenc_amd import binding as B, sharding, synth, tables as T
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def ctx(monkeypatch):
+@pytest.fixture(params=["device_counter", "per_xcd"])
+def ctx(monkeypatch, request):
+    """Both ways the writer's workgroups come by their tile numbers: from one counter (what pictures of this size
+    get), and by XCD in chunks (what large pictures get; the switch sends every picture there)."""
     monkeypatch.setenv("JPEGENC_WRITER", "dense")
+    if request.param == "per_xcd":
+        monkeypatch.setenv("JPEGENC_DENSE_PER_XCD_FROM", "0")
     c = B.Context(0)
     yield c
     c.close()
