@@ -65,6 +65,27 @@ def test_histograms_counted_on_groups(ctx, scheme):
         assert np.array_equal(ctx.histograms(), enc.hist), (scheme, w, h, kind, tname, ri)
 
 
+@pytest.mark.parametrize("scheme", ["444", "420", "422"])
+def test_histograms_of_tiles_without_an_empty_group(ctx, scheme):
+    """Dense content: k_histogram_tiles takes the tiles all of whose groups hold something block by block
+    (histogram_full_tile).  Noise through tables of ones (hardly a zero), through fine tables (zeros here and there,
+    counted one by one), tiles that end in the middle, intervals that restart the DC prediction inside tiles, and a
+    picture whose lower part is photographic so that both kinds of tiles meet in one histogram."""
+    for (w, h, tname, ri) in [(512, 512, "ones", 0), (517, 261, "ones", 5), (250, 130, "ones", 1), (640, 200, "ps12", 0),
+                              (331, 203, "ps12", 9), (1040, 72, "ones", 0)]:
+        img = synth.generate("noise", w, h, seed=w + 7 * h)
+        if (w, h) == (512, 512):
+            img[300:] = synth.generate("natural", w, h - 300, seed=5)
+        qt = T.NAMED_TABLES[tname]
+        enc = O.encode(img, T.SCHEMES[scheme], qt, restart_interval=ri)
+        prm = B.make_params(w, h, T.SCHEMES[scheme], qt, restart_interval=ri)
+        ctx.begin(prm)
+        ctx.upload_pixels(img)
+        ctx.transform()
+        assert np.array_equal(ctx.histograms(), enc.hist), (scheme, w, h, tname, ri)
+        assert ctx.encode_host(img, prm) == enc.jpeg, (scheme, w, h, tname, ri)
+
+
 @pytest.mark.parametrize("tile", [256, 16])
 @pytest.mark.parametrize("ri", [3, 8, 40, 1000])
 def test_restart_intervals(ctx, ri, tile):
