@@ -24,6 +24,7 @@ cases = [("16k natural 420 rst", 16384, 16384, "420", 90, "natural", 1024, 1),
          ("8k noise 444 q100", 8192, 8192, "444", 100, "noise", 0, 1),
          ("4k noise 420 q100", 4096, 4096, "420", 100, "noise", 64, 1),
          ("8k noise 420 q100 rst 3", 8192, 8192, "420", 100, "noise", 3, 1),
+         ("4k noise 444 q100 rst 5 (the smallest picture with tile numbers by XCD)", 4096, 4096, "444", 100, "noise", 5, 1),
          ("batch 16 x 1080p noise q100 444", 1920, 1080, "444", 100, "noise", 0, 16),
          ("batch 64 x 1080p", 1920, 1080, "420", 90, "natural", 0, 64),
          ("batch 12 x 640x480 444", 640, 480, "444", 75, "natural", 0, 12)]
