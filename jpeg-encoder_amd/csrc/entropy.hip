@@ -724,10 +724,10 @@ static hipError_t launch_histogram_tiles(const KGeom& g, const int16_t* d_coef, 
     // (Diagnostic switch JPEGENC_HIST_GRID: another number.)
     static const long long gridCap = getenv("JPEGENC_HIST_GRID") ? atoll(getenv("JPEGENC_HIST_GRID")) : 1280;
     const long long cap = g.batch > 1 ? (4096 / g.batch > 8 ? 4096 / g.batch : 8) : gridCap;
-    // Up to six workgroups per CU are taken as they are (one tile per wave, nobody takes a second turn:
-    // 8192 x 8192 4:2:0, 1536 workgroups, 102 -> 99 us).  Beyond that, giving every workgroup the same number
-    // of turns was measured and is worse than the plain cap (16384 x 16384: 1229 workgroups 153 us, 1280: 141).
-    if (grid > cap && !(g.batch == 1 && grid <= 1536)) grid = cap;
+    // (Giving every workgroup the same number of turns was measured and is worse than the plain cap -- 16384 x 16384:
+    // 1229 workgroups 153 us, 1280: 141 -- and so is, since full tiles are counted in registers, taking up to six
+    // workgroups per CU as they are: 8192 x 8192 4:2:0 noise, 1536 workgroups 83 us, 1280: 77.)
+    if (grid > cap) grid = cap;
     HistogramExport none = {nullptr, 0, nullptr, nullptr, nullptr};
     if (ex != nullptr) ex->expected += (unsigned long long)grid;
     HistogramExport given = ex != nullptr ? *ex : none;
