@@ -95,7 +95,7 @@ def cpu_baseline(rgb, width, height, frames, scheme, qt, restart_interval, gpu_f
     what = ("the whole %dx%d workload image" % (width, height)) if not frames else \
         ("the first %d of the %d frames, one after the other" % (sample, frames))
     return {"value": round(sample * width * height / 1e6 / best, 2), "unit": "MP/s", "cores": threads,
-            "kind": "avx2+openmp port",
+            "kind": "port", "implementation": "AVX2 + OpenMP restatement of the reference's path (oracle/jpeg_oracle_avx2.cpp)",
             "sample": "%s, same scheme, tables and restart interval; encode call only (pixels in host memory -> file "
                       "in host memory), best of %d runs, OpenMP threads=%d" % (what, runs, threads),
             "file_equals_gpu_file": same}

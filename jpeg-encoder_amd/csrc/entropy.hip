@@ -1115,6 +1115,43 @@ __device__ __forceinline__ u32 block_exclusive_scan_dpp(u32 v, u32* lds, u32& to
     return base + inc - v;
 }
 
+// A lane's sixteen stream bytes (the first `valid` of them count) with a zero byte behind every 0xFF flagged in
+// `mask`, stored at dst, whatever its alignment: the lane's output as a string of bytes in registers (stores to memory
+// need no alignment on this target, so no lane has to know its neighbours' bytes).
+__device__ __forceinline__ void stuff_store_own(const uint4& q, u32 mask, int valid, uint8_t* __restrict__ dst) {
+    u32 str[8] = {q.x, q.y, q.z, q.w, 0u, 0u, 0u, 0u};
+    u32 inserted = 0;
+    for (u32 todo = mask; todo != 0; todo &= todo - 1, ++inserted) {
+        const u32 z = (u32)__builtin_ctz(todo) + inserted + 1;   // index the zero byte gets
+        const u32 w = z >> 2, r = z & 3u;
+        const u32 keep = (1u << (8 * r)) - 1u, above = 0xffffff00u << (8 * r);
+#pragma unroll
+        for (int i = 7; i >= 0; --i) {   // bytes from z on move up by one
+            const u32 up = i > 0 ? __builtin_amdgcn_alignbyte(str[i], str[i > 0 ? i - 1 : 0], 3) : str[0] << 8;
+            if ((u32)i > w) str[i] = up;
+            else if ((u32)i == w) str[i] = (str[i] & keep) | (up & above);
+        }
+    }
+    // byte b of the string, for the few bytes that are not stored as whole words
+    auto byte_at = [&](u32 b) {
+        const u32 i = b >> 2;
+        const u32 lo4 = i & 2u ? (i & 1u ? str[3] : str[2]) : (i & 1u ? str[1] : str[0]);
+        const u32 hi4 = i & 2u ? (i & 1u ? str[7] : str[6]) : (i & 1u ? str[5] : str[4]);
+        return (uint8_t)((i & 4u ? hi4 : lo4) >> (8 * (b & 3u)));
+    };
+    if (valid == 16) {
+        const uint4 first = make_uint4(str[0], str[1], str[2], str[3]);
+        __builtin_memcpy(dst, &first, 16);
+        // what the insertions pushed out of the first sixteen bytes: one byte as a rule
+        if (inserted != 0) {
+            dst[16] = (uint8_t)str[4];
+            for (u32 b = 17; b < 16u + inserted; ++b) dst[b] = byte_at(b);
+        }
+    } else {   // the stream's last bytes
+        for (u32 b = 0; b < (u32)valid + inserted; ++b) dst[b] = byte_at(b);
+    }
+}
+
 template <bool kBatch, bool kOwnBytes>
 __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __restrict__ buf,
                                                      const u64* __restrict__ ivOff, const u32* __restrict__ ffCount,
@@ -1187,42 +1224,7 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
                 }
             } else if (valid > 0) {
                 if (kOwnBytes) {
-                    // The lane's output as a string of bytes in registers: its sixteen bytes with a zero
-                    // byte inserted behind every 0xFF that is data, stored at its own byte position
-                    // (stores to memory need no alignment on this target, so no lane has to know its
-                    // neighbours' bytes).
-                    u32 str[8] = {q.x, q.y, q.z, q.w, 0u, 0u, 0u, 0u};
-                    u32 inserted = 0;
-                    for (u32 todo = mask; todo != 0; todo &= todo - 1, ++inserted) {
-                        const u32 z = (u32)__builtin_ctz(todo) + inserted + 1;   // index the zero byte gets
-                        const u32 w = z >> 2, r = z & 3u;
-                        const u32 keep = (1u << (8 * r)) - 1u, above = 0xffffff00u << (8 * r);
-#pragma unroll
-                        for (int i = 7; i >= 0; --i) {   // bytes from z on move up by one
-                            const u32 up = i > 0 ? __builtin_amdgcn_alignbyte(str[i], str[i > 0 ? i - 1 : 0], 3) : str[0] << 8;
-                            if ((u32)i > w) str[i] = up;
-                            else if ((u32)i == w) str[i] = (str[i] & keep) | (up & above);
-                        }
-                    }
-                    uint8_t* dst = out + base + (long long)local;
-                    // byte b of the string, for the few bytes that are not stored as whole words
-                    auto byte_at = [&](u32 b) {
-                        const u32 i = b >> 2;
-                        const u32 lo4 = i & 2u ? (i & 1u ? str[3] : str[2]) : (i & 1u ? str[1] : str[0]);
-                        const u32 hi4 = i & 2u ? (i & 1u ? str[7] : str[6]) : (i & 1u ? str[5] : str[4]);
-                        return (uint8_t)((i & 4u ? hi4 : lo4) >> (8 * (b & 3u)));
-                    };
-                    if (valid == 16) {
-                        const uint4 first = make_uint4(str[0], str[1], str[2], str[3]);
-                        __builtin_memcpy(dst, &first, 16);
-                        // what the insertions pushed out of the first sixteen bytes: one byte as a rule
-                        if (inserted != 0) {
-                            dst[16] = (uint8_t)str[4];
-                            for (u32 b = 17; b < 16u + inserted; ++b) dst[b] = byte_at(b);
-                        }
-                    } else {   // the stream's last bytes
-                        for (u32 b = 0; b < (u32)valid + inserted; ++b) dst[b] = byte_at(b);
-                    }
+                    stuff_store_own(q, mask, valid, out + base + (long long)local);
                 } else {
                     // The lane's output as a string of bytes in registers: its sixteen bytes, then the
                     // four that follow them in the stream (the lane owns every output dword that
@@ -1304,6 +1306,100 @@ __global__ __launch_bounds__(256) void k_stuff_bytes(KGeom g, const uint8_t* __r
         }
         const u64 chunkBytes = bytes - (u64)c0 < (u64)kStuffChunk ? bytes - (u64)c0 : (u64)kStuffChunk;
         ffBefore += total - chunkBytes;   // what the chunk wrote beyond its own bytes
+    }
+}
+
+// The same for long streams of one image, a wave per chunk and no workgroup: the wave's lanes take a chunk as two
+// halves of two rows of 1 KiB each, sixteen bytes per lane and row, the output offsets come from a scan inside the
+// wave (both rows in one, sixteen bits each), and nothing is waited for but memory -- the scan over a workgroup
+// cost two barriers per chunk, with every wave's loads and stores behind them.  The stuffing bytes in front of the
+// wave's first chunk come from the group sums (which the host therefore always asks for).
+__global__ __launch_bounds__(64) void k_stuff_waves(KGeom g, const uint8_t* __restrict__ buf, const u64* __restrict__ ivOff,
+                                                    const u32* __restrict__ ffCount, const u64* __restrict__ groupSum,
+                                                    u64* __restrict__ result, uint8_t* __restrict__ out, long long prefixLen,
+                                                    long long outCapacity, u64* __restrict__ hostResult) {
+    const int lane = threadIdx.x;
+    const u64 bytes = result[2];
+    const long long chunks = (long long)((bytes + kStuffChunk - 1) / kStuffChunk);
+    const long long chFirst = chunks * blockIdx.x / gridDim.x;
+    const long long chEnd = chunks * (blockIdx.x + 1) / gridDim.x;
+    if (chunks == 0 && blockIdx.x == 0 && lane == 0 && hostResult) {   // (see k_stuff_bytes)
+        hostResult[0] = (u64)prefixLen;
+        hostResult[3] = result[1] & ~1ull;
+    }
+    if (chFirst >= chEnd) return;
+    constexpr long long kHalf = kStuffChunk / 2;
+    uint4 qNext[2];
+    u32 countNext = 0;
+    auto fetch = [&](long long half) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const long long i0 = half * kHalf + r * 1024 + lane * 16;
+            qNext[r] = make_uint4(0, 0, 0, 0);
+            if ((u64)i0 < bytes) qNext[r] = *(const uint4*)(buf + i0);
+        }
+        countNext = ffCount[half >> 1];
+    };
+    fetch(2 * chFirst);
+    u64 ffBefore;
+    {
+        u64 v = 0;
+        const long long grp = chFirst / kChunkGroup;
+        for (long long i = lane; i < grp; i += 64) v += groupSum[i];
+        const long long c = grp * kChunkGroup + lane;
+        if (c < chFirst) v += ffCount[c] & kChunkCountMask;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += (u64)__shfl_xor((long long)v, d, 64);
+        ffBefore = v;
+    }
+    bool full = false;
+    for (long long half = 2 * chFirst; half < 2 * chEnd; ++half) {
+        const long long h0 = half * kHalf;
+        const uint4 q[2] = {qNext[0], qNext[1]};
+        const bool noMarkers = countNext <= kChunkCountMask;   // no marker begins in this chunk
+        if (half + 1 < 2 * chEnd) fetch(half + 1);
+        int valid[2];
+        u32 mask[2], n[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const long long i0 = h0 + r * 1024 + lane * 16;
+            valid[r] = 0;
+            mask[r] = 0;
+            if ((u64)i0 < bytes) {
+                valid[r] = (int)(bytes - (u64)i0 < 16 ? bytes - (u64)i0 : 16);
+                mask[r] = stuff_mask(g, buf, ivOff, bytes, i0, q[r], noMarkers);
+            }
+            n[r] = (u32)valid[r] + (u32)__popc(mask[r]);
+        }
+        // (a row puts out 2 KiB at most: sixteen bits hold every sum)
+        const u32 incl = wave_scan_add(n[0] | (n[1] << 16));
+        const u32 tot = (u32)__builtin_amdgcn_readlane(incl, 63);
+        const u32 total = (tot & 0xffffu) + (tot >> 16);
+        const u32 local[2] = {(incl & 0xffffu) - n[0], (tot & 0xffffu) + (incl >> 16) - n[1]};
+        const long long base = prefixLen + h0 + (long long)ffBefore;
+        if (base + (long long)total > outCapacity) {
+            full = true;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                if (valid[r] > 0) stuff_store_own(q[r], mask[r], valid[r], out + base + (long long)local[r]);
+        }
+        const u64 halfBytes = (u64)h0 >= bytes ? 0ull : (bytes - (u64)h0 < (u64)kHalf ? bytes - (u64)h0 : (u64)kHalf);
+        ffBefore += total - halfBytes;   // what the half wrote beyond its own bytes
+    }
+    if (lane == 0) {
+        if (full) {
+            atomicOr((unsigned long long*)&result[1], 1ull);
+            if (hostResult) hostResult[1] = 1;
+        }
+        if (chEnd == chunks) {   // the stream's last chunk was this wave's
+            const u64 end = (u64)prefixLen + bytes + ffBefore;
+            result[0] = end;
+            if (hostResult) {
+                hostResult[0] = end;
+                hostResult[3] = result[1] & ~1ull;   // what the bit writer flagged (it has finished)
+            }
+        }
     }
 }
 
@@ -1467,8 +1563,9 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
         groupSum = ws.groupSum;
     }
     // Streams of several chunks per workgroup store every lane's own bytes (see k_stuff_bytes).
-    // (Diagnostic switch JPEGENC_STUFF_FORM=0 / 1: always the aligned form / always the other.)
-    static const char* stuffForm = getenv("JPEGENC_STUFF_FORM");
+    // (Diagnostic switch JPEGENC_STUFF_FORM=0 / 1: always the aligned form / always the other; read at every call so
+    // that a test can set it.)
+    const char* stuffForm = getenv("JPEGENC_STUFF_FORM");
     const bool ownBytes = stuffForm ? stuffForm[0] == '1' : chunkBound >= 4 * gridCap;
     if (bo) {
         hipLaunchKernelGGL(k_image_ff_start, dim3((unsigned)(g.batch + 1)), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
@@ -1482,7 +1579,15 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
                                ws.ffCount, groupSum, ws.result, bo->out, 0, 0, *bo, nullptr);
     } else {
         BatchOutput none = {};
-        if (ownBytes)
+        // Streams long enough to have group sums take the wave-per-chunk form, six waves per SIMD (8192 x 8192 noise
+        // 4:4:4, 196 MB: 104 -> 87 us with 6144 waves, 99 with 4096, 92 with 5120, 94 with 8192; 4:2:0: 59 -> 53 us;
+        // the 57 MB of the 16384 x 16384 picture would gain the 4 us that the group sums cost it).
+        // (Diagnostic switch JPEGENC_STUFF_WAVES: another number of waves, 0 for the other forms.)
+        static const long long waveGrid = getenv("JPEGENC_STUFF_WAVES") ? atoll(getenv("JPEGENC_STUFF_WAVES")) : 6144;
+        if (ownBytes && groupSum != nullptr && waveGrid > 0)
+            hipLaunchKernelGGL(k_stuff_waves, dim3((unsigned)(chunkBound < waveGrid ? chunkBound : waveGrid)), dim3(64), 0, s, g, ws.unstuffed,
+                               ws.ivOff, ws.ffCount, groupSum, ws.result, d_out, prefixLen, outCapacity, ws.hostResult);
+        else if (ownBytes)
             hipLaunchKernelGGL((k_stuff_bytes<false, true>), dim3((unsigned)chunkGrid), dim3(256), 0, s, g, ws.unstuffed, ws.ivOff,
                                ws.ffCount, groupSum, ws.result, d_out, prefixLen, outCapacity, none, ws.hostResult);
         else

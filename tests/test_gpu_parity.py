@@ -368,3 +368,27 @@ def test_tables_from_a_histogram_that_undercounts(ctx, writer, monkeypatch):
         assert d_out[:n].cpu().numpy().tobytes() == want
     finally:
         c.close()
+
+
+def test_stuffing_by_waves_on_small_streams(monkeypatch):
+    """k_stuff_waves, which long streams get (a wave per 4 KiB chunk, group sums in front), on pictures of every
+    size: streams that end in the middle of a row of a chunk, markers of restart intervals inside chunks, runs of
+    0xFF bytes (saturated blocks), and a stream of a single chunk.  BitBuffer.cpp:128-204 is what the bytes must be."""
+    monkeypatch.setenv("JPEGENC_STUFF_FORM", "1")
+    monkeypatch.setenv("JPEGENC_GROUP_SUMS_FROM", "1")
+    ctx = B.Context(0)
+    try:
+        for (w, h, kind, scheme, q, ri) in [(640, 480, "noise", "444", 100, 0), (333, 270, "noise", "420", 100, 7), (1000, 700, "natural", "422", 90, 63),
+                                            (64, 40, "noise", "444", 100, 1), (1920, 1080, "noise", "420", 95, 120), (2049, 130, "natural", "444", 75, 0)]:
+            img = synth.generate(kind, w, h, seed=w + h)
+            qt = T.quality_tables(q)
+            want = O.encode(img, T.SCHEMES[scheme], qt, restart_interval=ri).jpeg
+            prm = B.make_params(w, h, T.SCHEMES[scheme], qt, restart_interval=ri)
+            assert ctx.encode_host(img, prm) == want, (w, h, kind, scheme, q, ri)
+        # every byte 0xFF for long stretches: white noise through tables of ones has runs of them, a flat picture none
+        img = np.full((256, 256, 3), 255, np.uint8)
+        img[::2, ::3] = 0
+        qt = T.NAMED_TABLES["ones"]
+        assert ctx.encode_host(img, B.make_params(256, 256, T.SCHEMES["444"], qt)) == O.encode(img, T.SCHEMES["444"], qt).jpeg
+    finally:
+        ctx.close()
