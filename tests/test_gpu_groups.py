@@ -84,6 +84,13 @@ def test_histograms_of_tiles_without_an_empty_group(ctx, scheme):
         ctx.transform()
         assert np.array_equal(ctx.histograms(), enc.hist), (scheme, w, h, tname, ri)
         assert ctx.encode_host(img, prm) == enc.jpeg, (scheme, w, h, tname, ri)
+    # frames of a batch: every frame's tiles count into the frame's own histograms
+    qt = T.NAMED_TABLES["ones"]
+    frames = np.stack([synth.generate("noise" if k != 1 else "natural", 264, 200, seed=90 + k) for k in range(4)])
+    prm = B.make_params(264, 200, T.SCHEMES[scheme], qt)
+    got = ctx.encode_batch_host(frames, prm, 1 << 19)
+    for k in range(4):
+        assert got[k] == O.encode(frames[k], T.SCHEMES[scheme], qt).jpeg, (scheme, k)
 
 
 @pytest.mark.parametrize("tile", [256, 16])
