@@ -1497,7 +1497,9 @@ static hipError_t run_entropy_stage(const KGeom& g, const int16_t* d_coef, const
     long long prepWork = clear16 > tileCount / 2 ? clear16 : tileCount / 2;
     if (chunkBound / 4 > prepWork) prepWork = chunkBound / 4;
     long long prepGrid = prepWork / (256 * 4);
-    prepGrid = prepGrid < 1 ? 1 : (prepGrid > 2048 ? 2048 : prepGrid);
+    // (At least eight workgroups: the table image comes from pinned host memory, a word per thread, and a workgroup
+    // that takes several turns waits for the bus every time -- 4096 x 4096 through the dense writer: 13.5 -> 5 us.)
+    prepGrid = prepGrid < 8 ? 8 : (prepGrid > 2048 ? 2048 : prepGrid);
     // Tile states: the chaining tiles start from zeros (and a zero ticket counter behind them); deferred
     // tiles write theirs before anybody reads them, and only the word k_tile_positions counts its waves
     // off with has to be zero.
